@@ -1,0 +1,481 @@
+"""Host-side scene vocabulary of the reference, flattened for the GPU path.
+
+The class names, constructor argument order and meaning follow the reference's scene API so
+that scene-authoring code reads the same:
+
+    sphere(center, radius, material)                      sphere.h:13, cuda/sphere.h:16
+    xy_rect(x0,x1,y0,y1,k,mat) / xz_rect / yz_rect        cuda/rect.h:19,66,112
+    sceneobject_list.add / clear                          sceneobject_list.h:16-21
+    bvh_node(list)                                        cuda/bvh.h:18
+    lambertian(color|texture) metal(color,fuzz) dielectric(ir)
+                                                          material.h:19,40,56
+    lambertian_bg(color|texture) diffuse_light(color|texture)
+                                                          cuda/material.h:37-38,107-109
+    rgb_color(color) checker_texture(c1,c2 | even,odd) image_texture(width,height,texels)
+                                                          cuda/texture.h:22,39-41,61
+    camera(lookfrom, lookat, vup, vfov, aspect_ratio, aperture, focus_dist)
+                                                          camera.h:19-20
+
+Nothing here touches the GPU: `flatten()` turns a sceneobject_list into the flat arrays that
+`rt_upload_scene` takes (see include/rt.h), in list order, de-duplicating materials and
+textures by object identity.
+"""
+from __future__ import annotations
+
+import math
+import os
+from dataclasses import dataclass, field
+
+import numpy as np
+
+# primitive / material / texture / background tags: the values of include/rt.h
+RT_SPHERE, RT_XY_RECT, RT_XZ_RECT, RT_YZ_RECT = 0, 1, 2, 3
+RT_LAMBERTIAN, RT_METAL, RT_DIELECTRIC, RT_DIFFUSE_LIGHT, RT_LAMBERTIAN_BG = 0, 1, 2, 3, 4
+RT_TEX_SOLID, RT_TEX_CHECKER, RT_TEX_IMAGE = 0, 1, 2
+RT_BG_SKY, RT_BG_SOLID = 0, 1
+
+
+def vec3(x=0.0, y=0.0, z=0.0):
+    return (float(x), float(y), float(z))
+
+
+point3 = vec3
+color = vec3
+
+
+def _v(a):
+    a = tuple(float(x) for x in a)
+    if len(a) != 3:
+        raise ValueError("expected 3 components")
+    return a
+
+
+# ---- textures ------------------------------------------------------------------------
+
+class custom_texture:
+    pass
+
+
+class rgb_color(custom_texture):
+    def __init__(self, *c):
+        self.color_value = _v(c[0] if len(c) == 1 else c)
+
+
+class checker_texture(custom_texture):
+    def __init__(self, even, odd):
+        self.even = even if isinstance(even, custom_texture) else rgb_color(even)
+        self.odd = odd if isinstance(odd, custom_texture) else rgb_color(odd)
+
+
+class image_texture(custom_texture):
+    """texels: uint8 array [height, width, 3], top row first (what the reference's loader
+    hands to the device, cuda/main.cu:393-406)."""
+
+    def __init__(self, width, height, texels):
+        texels = np.ascontiguousarray(texels, dtype=np.uint8)
+        if texels.shape != (height, width, 3):
+            raise ValueError(f"texels must be [{height},{width},3] uint8, got {texels.shape}")
+        self.texture_width, self.texture_height, self.texels = int(width), int(height), texels
+
+
+# ---- materials --------------------------------------------------------------------------
+
+class material:
+    pass
+
+
+def _tex_or_color(a):
+    return a if isinstance(a, custom_texture) else _v(a)
+
+
+class lambertian(material):
+    def __init__(self, a):
+        self.albedo = _tex_or_color(a)
+
+
+class lambertian_bg(material):
+    def __init__(self, a):
+        self.albedo = _tex_or_color(a)
+
+
+class metal(material):
+    def __init__(self, a, f):
+        self.albedo = _v(a)
+        self.fuzz = float(f) if f < 1 else 1.0        # material.h:40
+
+
+class dielectric(material):
+    def __init__(self, index_of_refraction):
+        self.ir = float(index_of_refraction)
+
+
+class diffuse_light(material):
+    def __init__(self, a):
+        self.emit = _tex_or_color(a)
+
+
+# ---- objects ----------------------------------------------------------------------------------
+
+class sceneobject:
+    pass
+
+
+class sphere(sceneobject):
+    def __init__(self, cen, r, m):
+        self.center, self.radius, self.mat_ptr = _v(cen), float(r), m
+
+
+class _rect(sceneobject):
+    kind = None
+
+    def __init__(self, a0, a1, b0, b1, k, mat):
+        self.a0, self.a1, self.b0, self.b1, self.k, self.mat = (float(a0), float(a1), float(b0),
+                                                               float(b1), float(k), mat)
+
+
+class xy_rect(_rect):
+    kind = RT_XY_RECT
+
+
+class xz_rect(_rect):
+    kind = RT_XZ_RECT
+
+
+class yz_rect(_rect):
+    kind = RT_YZ_RECT
+
+
+class sceneobject_list(sceneobject):
+    def __init__(self, obj=None):
+        self.objects = []
+        if obj is not None:
+            if isinstance(obj, (list, tuple)):
+                self.objects.extend(obj)
+            else:
+                self.add(obj)
+
+    def clear(self):
+        self.objects.clear()
+
+    def add(self, obj):
+        self.objects.append(obj)
+
+
+class bvh_node(sceneobject):
+    """Grouping marker kept for source compatibility (cuda/bvh.h:18).  The GPU path builds one
+    BVH over the whole flattened scene, so a bvh_node only contributes its members."""
+
+    def __init__(self, scene_list, rng=None):
+        self.objects = list(scene_list.objects)
+
+
+# ---- camera ------------------------------------------------------------------------------------
+
+class camera:
+    """camera.h:19-38; the optional `angles` and the mutators are the CUDA tree's
+    (cuda/camera.h:29-117) and work in float32 like the original."""
+
+    def __init__(self, lookfrom, lookat, vup, vfov, aspect_ratio, aperture, focus_dist,
+                 angles=(0.0, 0.0, 0.0)):
+        self.look_from, self.look_at, self.vup = _v(lookfrom), _v(lookat), _v(vup)
+        self.angles = _v(angles)
+        self.vfov, self.aspect_ratio = float(vfov), float(aspect_ratio)
+        self.aperture, self.focus_dist = float(aperture), float(focus_dist)
+
+    def desc(self):
+        return dict(lookfrom=self.look_from, lookat=self.look_at, vup=self.vup, vfov=self.vfov,
+                    aspect=self.aspect_ratio, aperture=self.aperture, focus_dist=self.focus_dist)
+
+    def compute_camera_scene(self):
+        """No cached basis on the host: rt_set_camera derives it (include/rt.h)."""
+        return self.desc()
+
+    def translate_camera(self, x, y, z):                  # cuda/camera.h:59-63
+        f = np.float32
+        lf = [f(c) for c in self.look_from]
+        self.look_from = (float(lf[0] + f(x)), float(lf[1] + f(y)), float(lf[2] + f(z)))
+
+    @staticmethod
+    def _rads(deg):                                        # cuda/utils.h:17
+        f = np.float32
+        return f(f(deg) * f(3.1415926535897932385) / f(180.0))
+
+    def _rot(self, axis_angle, new_angle, i, j, sign):
+        f = np.float32
+        r = self._rads(f(new_angle) - f(self.angles[axis_angle]))
+        c, s = f(math.cos(float(r))), f(math.sin(float(r)))
+        # float cos/sin of a float argument, rounded to float like cosf/sinf
+        lf = [f(v) for v in self.look_from]
+        ni = f(lf[i] * c) - f(sign) * f(lf[j] * s)
+        nj = f(sign) * f(lf[i] * s) + f(lf[j] * c)
+        lf[i], lf[j] = f(ni), f(nj)
+        self.look_from = tuple(float(v) for v in lf)
+        a = list(self.angles)
+        a[axis_angle] = float(f(new_angle))
+        self.angles = tuple(a)
+
+    def rotate_camera_x(self, new_x_angle):               # cuda/camera.h:69-81 (xy-plane)
+        self._rot(0, new_x_angle, 0, 1, 1.0)
+
+    def rotate_camera_y(self, new_y_angle):               # cuda/camera.h:87-99 (xz-plane)
+        f = np.float32
+        r = self._rads(f(new_y_angle) - f(self.angles[1]))
+        c, s = f(math.cos(float(r))), f(math.sin(float(r)))
+        x, y, z = (f(v) for v in self.look_from)
+        nx = f(f(x * c) + f(z * s))
+        nz = f(f(z * c) - f(x * s))
+        self.look_from = (float(nx), float(y), float(nz))
+        self.angles = (self.angles[0], float(f(new_y_angle)), self.angles[2])
+
+    def rotate_camera_z(self, new_z_angle):               # cuda/camera.h:105-117 (yz-plane)
+        self._rot(2, new_z_angle, 1, 2, 1.0)
+
+
+def update_scene(cam: camera, frame: int):
+    """Per-frame camera animation of cuda/main.cu:220-279 (rotate_scene: :206-217)."""
+    f = np.float32
+
+    def rotate(ax, ay, az):
+        if ax != cam.angles[0]:
+            cam.rotate_camera_x(ax)
+        if ay != cam.angles[1]:
+            cam.rotate_camera_y(ay)
+        if az != cam.angles[2]:
+            cam.rotate_camera_z(az)
+
+    ax, ay, az = (f(a) for a in cam.angles)
+    d = f(0.125)
+    if frame == 0:
+        return
+    if frame < 200:
+        rotate(float(ax), float(f(ay + d)), float(az))
+    elif frame < 400:
+        rotate(float(ax), float(f(ay - d)), float(az))
+    elif frame < 500:
+        rotate(float(f(ax + d)), float(ay), float(az))
+        cam.translate_camera(-0.025, 0.025, 0.0)
+    elif frame < 600:
+        rotate(float(f(ax - d)), float(ay), float(az))
+        cam.translate_camera(0.025, -0.025, 0.0)
+
+
+# ---- flattening -------------------------------------------------------------------------------------
+
+@dataclass
+class FlatScene:
+    prim_type: np.ndarray
+    prim_geom: np.ndarray      # [n,6] float64: sphere cx cy cz r 0 0 | rect a0 a1 b0 b1 k 0
+    prim_mat: np.ndarray
+    mat_type: np.ndarray
+    mat_param: np.ndarray      # [m,5] float64: albedo rgb, fuzz, ir
+    mat_tex: np.ndarray
+    tex_type: np.ndarray
+    tex_color: np.ndarray      # [t,3] float64
+    tex_a: np.ndarray
+    tex_b: np.ndarray
+    tex_off: np.ndarray
+    texels: np.ndarray         # uint8 blob
+    background: int = RT_BG_SKY
+    bg_color: tuple = (0.0, 0.0, 0.0)
+    meta: dict = field(default_factory=dict)
+
+    @property
+    def n_prims(self):
+        return int(self.prim_type.shape[0])
+
+
+def _walk(obj, out):
+    if isinstance(obj, (sceneobject_list, bvh_node)):
+        for o in obj.objects:
+            _walk(o, out)
+    elif isinstance(obj, (sphere, _rect)):
+        out.append(obj)
+    else:
+        raise TypeError(f"not a scene object: {type(obj).__name__}")
+
+
+def flatten(world, background=RT_BG_SKY, bg_color=(0.0, 0.0, 0.0)) -> FlatScene:
+    prims = []
+    _walk(world, prims)
+    mats, mat_ids = [], {}
+    texs, tex_ids = [], {}
+    blobs, blob_bytes = [], 0
+
+    def tex_id(t):
+        nonlocal blob_bytes
+        if id(t) in tex_ids:
+            return tex_ids[id(t)]
+        if isinstance(t, rgb_color):
+            rec = (RT_TEX_SOLID, t.color_value, 0, 0, 0)
+        elif isinstance(t, checker_texture):
+            rec = (RT_TEX_CHECKER, (0, 0, 0), tex_id(t.even), tex_id(t.odd), 0)
+        elif isinstance(t, image_texture):
+            rec = (RT_TEX_IMAGE, (0, 0, 0), t.texture_width, t.texture_height, blob_bytes)
+            blobs.append(t.texels.reshape(-1))
+            blob_bytes += t.texels.size
+        else:
+            raise TypeError(f"not a texture: {type(t).__name__}")
+        tex_ids[id(t)] = len(texs)
+        texs.append(rec)
+        return tex_ids[id(t)]
+
+    def mat_id(m):
+        if id(m) in mat_ids:
+            return mat_ids[id(m)]
+        tex, alb, fuzz, ir = -1, (0.0, 0.0, 0.0), 0.0, 0.0
+        if isinstance(m, lambertian):
+            typ, a = RT_LAMBERTIAN, m.albedo
+        elif isinstance(m, lambertian_bg):
+            typ, a = RT_LAMBERTIAN_BG, m.albedo
+        elif isinstance(m, diffuse_light):
+            typ, a = RT_DIFFUSE_LIGHT, m.emit
+        elif isinstance(m, metal):
+            typ, a, fuzz = RT_METAL, m.albedo, m.fuzz
+        elif isinstance(m, dielectric):
+            typ, a, ir = RT_DIELECTRIC, (1.0, 1.0, 1.0), m.ir
+        else:
+            raise TypeError(f"not a material: {type(m).__name__}")
+        if isinstance(a, custom_texture):
+            tex = tex_id(a)
+        else:
+            alb = a
+        mat_ids[id(m)] = len(mats)
+        mats.append((typ, alb, fuzz, ir, tex))
+        return mat_ids[id(m)]
+
+    n = len(prims)
+    ptype = np.zeros(n, np.int32)
+    geom = np.zeros((n, 6), np.float64)
+    pmat = np.zeros(n, np.int32)
+    for i, o in enumerate(prims):
+        if isinstance(o, sphere):
+            ptype[i] = RT_SPHERE
+            geom[i, :4] = (*o.center, o.radius)
+            pmat[i] = mat_id(o.mat_ptr)
+        else:
+            ptype[i] = o.kind
+            geom[i, :5] = (o.a0, o.a1, o.b0, o.b1, o.k)
+            pmat[i] = mat_id(o.mat)
+    m = len(mats)
+    t = len(texs)
+    return FlatScene(
+        prim_type=ptype, prim_geom=geom, prim_mat=pmat,
+        mat_type=np.array([x[0] for x in mats], np.int32).reshape(m),
+        mat_param=np.array([[*x[1], x[2], x[3]] for x in mats], np.float64).reshape(m, 5),
+        mat_tex=np.array([x[4] for x in mats], np.int32).reshape(m),
+        tex_type=np.array([x[0] for x in texs], np.int32).reshape(t),
+        tex_color=np.array([x[1] for x in texs], np.float64).reshape(t, 3),
+        tex_a=np.array([x[2] for x in texs], np.int32).reshape(t),
+        tex_b=np.array([x[3] for x in texs], np.int32).reshape(t),
+        tex_off=np.array([x[4] for x in texs], np.int64).reshape(t),
+        texels=(np.concatenate(blobs) if blobs else np.zeros(0, np.uint8)),
+        background=int(background), bg_color=_v(bg_color))
+
+
+# ---- scenes of the benchmark configurations ----------------------------------------------------------
+
+_DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
+
+
+def rtiow_records():
+    """The reference's default scene (main.cc:37-85) as its g++ build produces it:
+    487 x (cx cy cz r type albedo(3) fuzz|ir).  The scene depends on the compiler's argument
+    evaluation order (main.cc:47,54), so it is stored, never re-derived."""
+    return np.load(os.path.join(_DATA, "rtiow_gxx_scene.npy"))
+
+
+def world_from_records(rec):
+    world = sceneobject_list()
+    for o in np.asarray(rec, dtype=np.float64).reshape(-1, 9):
+        typ = int(o[4])
+        if typ == 0:
+            m = lambertian(o[5:8])
+        elif typ == 1:
+            m = metal(o[5:8], o[8])
+        elif typ == 2:
+            m = dielectric(o[8])
+        else:
+            raise ValueError(f"unknown material tag {typ}")
+        world.add(sphere(o[0:3], o[3], m))
+    return world
+
+
+def rtiow_scene():
+    """main.cc's default world and camera (main.cc:97-106); aspect is the caller's."""
+    return world_from_records(rtiow_records())
+
+
+def rtiow_camera(aspect_ratio):
+    return camera((6, 3, -13), (0, 0, 0), (0, 1, 0), 20, aspect_ratio, 0.1, 10.0)
+
+
+def cornell_scene():
+    """The reference's 555-unit room (cuda/main.cu:162-170) with the lambertian walls of
+    cuda/main.cu:81-83 in place of the skybox images, the light of cuda/main.cu:67,166 and
+    the glass and metal r=30 spheres of cuda/main.cu:99-100.  Background is black."""
+    white = lambertian((.73, .73, .73))
+    red = lambertian((.65, .05, .05))
+    green = lambertian((.12, .45, .15))
+    light = diffuse_light((7, 7, 7))
+    w = sceneobject_list()
+    w.add(sphere((200, 278, 400), 30.0, dielectric(1.5)))
+    w.add(sphere((100, 278, 350), 30.0, metal((0.7, 0.6, 0.5), 0.0)))
+    w.add(yz_rect(0, 555, 0, 555, 555, green))
+    w.add(yz_rect(0, 555, 0, 555, 0, red))
+    w.add(xz_rect(75, 270, 76, 280, 554, light))
+    w.add(xz_rect(0, 555, 0, 555, 0, white))
+    w.add(xz_rect(0, 555, 0, 555, 555, white))
+    w.add(xy_rect(0, 555, 0, 555, 555, white))
+    return w
+
+
+def cornell_camera(aspect_ratio):
+    return camera((278, 278, -800), (278, 278, 0), (0, 1, 0), 40, aspect_ratio, 0.0, 10.0)
+
+
+def _philox_uniforms(n, seed):
+    """Host-side scene authoring stream: numpy's Philox, so a scene is identical on every box."""
+    return np.random.Generator(np.random.Philox(seed)).random(n)
+
+
+def procedural_image(width, height, seed=7):
+    """A deterministic RGB8 test image (no file or decoder involved)."""
+    y, x = np.mgrid[0:height, 0:width]
+    r = (x * 255 // max(width - 1, 1)).astype(np.uint8)
+    g = (y * 255 // max(height - 1, 1)).astype(np.uint8)
+    b = (((x // 8) + (y // 8)) % 2 * 200 + (seed % 50)).astype(np.uint8)
+    return np.stack([r, g, b], axis=-1)
+
+
+def stress_scene(n_spheres=1_000_000, seed=42, image=None):
+    """BVH stress scene: centres uniform in [-500,500] x [0,50] x [-500,500], radii U(0.1,0.5),
+    materials 80/15/5 % lambertian/metal/glass as main.cc:53-70; every tenth lambertian is
+    textured (alternating the sin-product checker of cuda/texture.h:44 and an image)."""
+    u = _philox_uniforms(n_spheres * 9, seed).reshape(n_spheres, 9)
+    if image is None:
+        image = procedural_image(256, 128)
+    img = image_texture(image.shape[1], image.shape[0], image)
+    chk = checker_texture((0.2, 0.3, 0.1), (0.9, 0.9, 0.9))
+    chk_m, img_m, glass = lambertian(chk), lambertian(img), dielectric(1.5)
+    w = sceneobject_list()
+    n_lamb = 0
+    for k in range(n_spheres):
+        c = (-500 + 1000 * u[k, 0], 50 * u[k, 1], -500 + 1000 * u[k, 2])
+        r = 0.1 + 0.4 * u[k, 3]
+        choose = u[k, 4]
+        if choose < 0.8:
+            n_lamb += 1
+            if n_lamb % 10 == 0:
+                m = chk_m if (n_lamb // 10) % 2 else img_m
+            else:
+                m = lambertian((u[k, 5] * u[k, 6], u[k, 6] * u[k, 7], u[k, 7] * u[k, 8]))
+        elif choose < 0.95:
+            m = metal((0.5 + 0.5 * u[k, 5], 0.5 + 0.5 * u[k, 6], 0.5 + 0.5 * u[k, 7]), 0.5 * u[k, 8])
+        else:
+            m = glass
+        w.add(sphere(c, r, m))
+    return w
+
+
+def stress_camera(aspect_ratio):
+    return camera((0, 60, -120), (0, 10, 0), (0, 1, 0), 40, aspect_ratio, 0.0, 10.0)
