@@ -1,0 +1,169 @@
+/* rt.h — C-ABI of the MI355X (gfx950) render path.
+ *
+ * The reference compiles scene and integrator into one translation unit (main.cc:3-8,
+ * cuda/main.cu:12-20) and has no plugin boundary of its own; this header is the boundary a
+ * maintainer would put where the reference launches its device work:
+ *
+ *   reference call site                                   entry point here
+ *   ---------------------------------------------------   -------------------------
+ *   create_world<<<1,1>>>        cuda/main.cu:39-189,520   rt_upload_scene
+ *   load_texture (H2D part)      cuda/main.cu:385-436      rt_upload_scene (texels)
+ *   camera ctor / update_scene   camera.h:19-38,
+ *                                cuda/main.cu:220-279,564  rt_set_camera
+ *   init_render + render<<<>>>   cuda/main.cu:281-355,582  rt_render / rt_render_host
+ *   pixel/sample loop, ray_color main.cc:10-35,111-126     rt_render / rt_render_host
+ *   world.hit (closest hit)      main.cc:18,
+ *                                sceneobject_list.h:26-39  rt_trace_primary
+ *   write_color / output_image   color.h:9-26,
+ *                                cuda/main.cu:358-383      rt_quantize
+ *   gpuErrchk                    cuda/main.cu:24-32        return codes + rt_last_error
+ *
+ * Conventions: every function returns RT_OK (0) or a negative rt_error; nothing exits or
+ * throws.  A context belongs to one GPU and is driven by one host thread at a time;
+ * different contexts may be driven concurrently.  All descriptors are deep-copied by the
+ * call that takes them.  Images are float4 per pixel, row 0 = BOTTOM row (the reference's
+ * framebuffer orientation, cuda/main.cu:338,364), rgb = sum (or mean) of sample radiance,
+ * a = number of samples.
+ */
+#ifndef RT_H
+#define RT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rt_context rt_context;
+
+typedef enum rt_error {
+    RT_OK = 0,
+    RT_ERR_INVALID = -1,      /* bad argument or descriptor */
+    RT_ERR_NO_DEVICE = -2,    /* no such GPU / not a gfx950 code object */
+    RT_ERR_HIP = -3,          /* a HIP runtime call failed (text in rt_last_error) */
+    RT_ERR_NO_SCENE = -4,     /* rt_upload_scene has not succeeded yet */
+    RT_ERR_NO_CAMERA = -5,    /* rt_set_camera has not succeeded yet */
+    RT_ERR_UNSUPPORTED = -6   /* valid request this build cannot serve (limits in rt_last_error) */
+} rt_error;
+
+/* primitive tags, in list order (sceneobject_list.h:21; rect kinds cuda/rect.h:8,54,101) */
+enum { RT_SPHERE = 0, RT_XY_RECT = 1, RT_XZ_RECT = 2, RT_YZ_RECT = 3 };
+/* material tags (material.h:15,35,51; cuda/material.h:33,103) */
+enum { RT_LAMBERTIAN = 0, RT_METAL = 1, RT_DIELECTRIC = 2, RT_DIFFUSE_LIGHT = 3, RT_LAMBERTIAN_BG = 4 };
+/* texture tags (cuda/texture.h:17,32,55) */
+enum { RT_TEX_SOLID = 0, RT_TEX_CHECKER = 1, RT_TEX_IMAGE = 2 };
+/* radiance of a ray that leaves the scene: the sky gradient of main.cc:30-34, or a constant */
+enum { RT_BG_SKY = 0, RT_BG_SOLID = 1 };
+/* closest-hit strategy: the reference's linear scan (sceneobject_list.h:26-39) or a BVH
+ * (cuda/bvh.h); both return the same hit */
+enum { RT_ACCEL_AUTO = 0, RT_ACCEL_LIST = 1, RT_ACCEL_BVH = 2 };
+
+typedef struct rt_scene_desc {
+    uint32_t struct_size;        /* sizeof(rt_scene_desc) */
+    int32_t n_prims;
+    const int32_t* prim_type;    /* [n_prims] RT_SPHERE.. */
+    const double* prim_geom;     /* [n_prims][6] sphere: cx cy cz r 0 0
+                                    rect:   a0 a1 b0 b1 k 0 (argument order of cuda/rect.h:19,66,112) */
+    const int32_t* prim_mat;     /* [n_prims] index into the material arrays */
+    int32_t n_mats;
+    const int32_t* mat_type;     /* [n_mats] */
+    const double* mat_param;     /* [n_mats][5] albedo r g b, fuzz, index of refraction */
+    const int32_t* mat_tex;      /* [n_mats] texture index, or -1: albedo is the colour */
+    int32_t n_tex;
+    const int32_t* tex_type;     /* [n_tex] */
+    const double* tex_color;     /* [n_tex][3] RT_TEX_SOLID */
+    const int32_t* tex_a;        /* RT_TEX_CHECKER: even texture | RT_TEX_IMAGE: width  */
+    const int32_t* tex_b;        /* RT_TEX_CHECKER: odd texture  | RT_TEX_IMAGE: height */
+    const int64_t* tex_off;      /* RT_TEX_IMAGE: byte offset of the image in texels */
+    const uint8_t* texels;       /* RGB8 rows, top row first (what stbi_load returns, cuda/main.cu:393) */
+    uint64_t texel_bytes;
+    int32_t background;          /* RT_BG_* */
+    float bg_color[3];
+    int32_t accel;               /* RT_ACCEL_* */
+    double wide_radius;          /* spheres with a larger radius are intersected in double
+                                    (0 = default 64.0) */
+} rt_scene_desc;
+
+/* camera.h:19-20 argument list */
+typedef struct rt_camera_desc {
+    double lookfrom[3], lookat[3], vup[3];
+    double vfov;                 /* vertical field of view, degrees */
+    double aspect, aperture, focus_dist;
+} rt_camera_desc;
+
+enum {
+    RT_FLAG_MEAN = 1u << 0,       /* rgb = mean radiance instead of the sum over samples */
+    RT_FLAG_NO_REFINE = 1u << 1,  /* skip the double-precision polish of the winning hit */
+    RT_FLAG_COUNTERS = 1u << 2    /* also count box/sphere/rect tests (slower; for the roofline) */
+};
+
+typedef struct rt_render_params {
+    uint32_t struct_size;        /* sizeof(rt_render_params) */
+    int32_t width, height;       /* full image, also when only some row tiles are rendered */
+    int32_t spp;                 /* samples rendered by this call */
+    int32_t sample_begin;        /* index of the first one (sample-split: rank g starts at g*spp) */
+    int32_t max_depth;           /* ray_bounce_limit (main.cc:94) */
+    uint64_t seed;
+    int32_t tile_rows;           /* row-tile sharding: rows are cut into tiles of tile_rows rows; */
+    int32_t tile_first;          /* this call renders tiles tile_first, tile_first+tile_step, ... */
+    int32_t tile_step;           /* and packs their rows in that order.  0,0,0 = whole image */
+    float t_min;                 /* main.cc:18 uses 0.001; 0 selects that */
+    uint32_t flags;              /* RT_FLAG_* */
+    int32_t lanes_per_pixel;     /* 1,2,4,...,64 lanes share a pixel's samples; 0 = choose */
+} rt_render_params;
+
+/* one closest-hit answer (hit_record of sceneobject.h:9-14 plus the object's list position) */
+typedef struct rt_hit {
+    int32_t id;                  /* position in the primitive list, -1 = miss */
+    float t;
+    float p[3];
+    float n[3];                  /* unit normal facing against the ray (sceneobject.h:16-23) */
+    int32_t front_face;
+    float u, v;                  /* surface coordinates (cuda/sphere.h:20-26, cuda/rect.h:43-44) */
+} rt_hit;
+
+typedef struct rt_stats {
+    uint64_t rays;               /* closest-hit queries (one per world.hit call, main.cc:18) */
+    uint64_t samples;            /* camera samples */
+    uint64_t box_tests, sphere_tests, sphere_hits, rect_tests, wide_tests, shades; /* RT_FLAG_COUNTERS */
+    float kernel_ms;             /* device time of the last render kernel (HIP events on its stream) */
+    int32_t lanes_per_pixel;     /* value the last render used */
+    int32_t accel;               /* RT_ACCEL_LIST or RT_ACCEL_BVH actually used */
+    int32_t bvh_nodes, bvh_depth;
+} rt_stats;
+
+int rt_create(int device, rt_context** out);
+void rt_destroy(rt_context* ctx);
+
+/* Use an existing hipStream_t for all device work of this context (NULL = the null stream). */
+int rt_set_stream(rt_context* ctx, void* hip_stream);
+
+int rt_upload_scene(rt_context* ctx, const rt_scene_desc* scene);
+int rt_set_camera(rt_context* ctx, const rt_camera_desc* camera);
+
+/* Rows this call would render for the given sharding (for sizing the output buffer). */
+int rt_shard_rows(int32_t height, int32_t tile_rows, int32_t tile_first, int32_t tile_step);
+
+/* Render into DEVICE memory: rgba_device holds rt_shard_rows(..) * width float4.  Asynchronous
+ * on the context's stream. */
+int rt_render(rt_context* ctx, const rt_render_params* params, float* rgba_device);
+/* Same into HOST memory; returns when the image is there. */
+int rt_render_host(rt_context* ctx, const rt_render_params* params, float* rgba_host);
+
+/* Closest hit of n explicit rays (host arrays; rays = n x (ox oy oz dx dy dz)). */
+int rt_trace_primary(rt_context* ctx, const float* rays_host, int32_t n, float t_min, rt_hit* hits_host);
+
+/* write_color (color.h:9-26) on device memory: n_pixels float4 sums -> n_pixels x 3 bytes. */
+int rt_quantize(rt_context* ctx, const float* rgba_device, int64_t n_pixels, int32_t spp,
+                uint8_t* rgb8_device);
+
+/* Waits for the context's stream, then reports the last render. */
+int rt_get_stats(rt_context* ctx, rt_stats* out);
+
+const char* rt_last_error(rt_context* ctx);
+const char* rt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_H */

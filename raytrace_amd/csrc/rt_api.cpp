@@ -1,0 +1,476 @@
+// C-ABI of the render path (include/rt.h): context, scene flattening into HBM, launches.
+#include "../../include/rt.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "rt_bvh.h"
+#include "rt_device.h"
+
+struct rt_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string error;
+
+    // scene
+    bool has_scene = false, has_camera = false;
+    rt::DScene scene{};
+    rt::DCamera camera{};
+    std::vector<void*> scene_allocs;
+    int accel_used = RT_ACCEL_LIST;
+    int bvh_nodes = 0, bvh_depth = 0;
+
+    // per-render state
+    unsigned long long* counters = nullptr;   // device, rt::kNumCounters
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    bool timed = false;
+    int last_k = 0;
+    float4* staging = nullptr;                // device image for rt_render_host
+    size_t staging_bytes = 0;
+};
+
+namespace {
+
+int fail(rt_context* ctx, int code, const std::string& msg) {
+    if (ctx) ctx->error = msg;
+    return code;
+}
+
+#define RT_HIP(ctx, call)                                                                     \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(ctx, RT_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));  \
+    } while (0)
+
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int dev) { (void)hipGetDevice(&prev); (void)hipSetDevice(dev); }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+void free_scene(rt_context* ctx) {
+    for (void* p : ctx->scene_allocs) (void)hipFree(p);
+    ctx->scene_allocs.clear();
+    ctx->has_scene = false;
+    ctx->scene = rt::DScene{};
+}
+
+template <typename T>
+int upload(rt_context* ctx, const std::vector<T>& host, const T** dev) {
+    *dev = nullptr;
+    if (host.empty()) return RT_OK;
+    void* p = nullptr;
+    RT_HIP(ctx, hipMalloc(&p, host.size() * sizeof(T)));
+    ctx->scene_allocs.push_back(p);
+    RT_HIP(ctx, hipMemcpy(p, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    *dev = static_cast<const T*>(p);
+    return RT_OK;
+}
+
+bool finite3(const double* v) { return std::isfinite(v[0]) && std::isfinite(v[1]) && std::isfinite(v[2]); }
+
+// camera.h:19-38 in double; the result is rounded to float once at the end.
+void build_camera(const rt_camera_desc& c, rt::DCamera* out) {
+    const double pi = 3.1415926535897932385;
+    double theta = c.vfov * pi / 180.0;
+    double h = std::tan(theta / 2);
+    double vh = 2.0 * h, vw = c.aspect * vh;
+    double w[3], u[3], v[3], t[3];
+    for (int a = 0; a < 3; a++) t[a] = c.lookfrom[a] - c.lookat[a];
+    double len = std::sqrt(t[0] * t[0] + t[1] * t[1] + t[2] * t[2]);
+    for (int a = 0; a < 3; a++) w[a] = (1 / len) * t[a];
+    double cr[3] = { c.vup[1] * w[2] - c.vup[2] * w[1], c.vup[2] * w[0] - c.vup[0] * w[2],
+                     c.vup[0] * w[1] - c.vup[1] * w[0] };
+    len = std::sqrt(cr[0] * cr[0] + cr[1] * cr[1] + cr[2] * cr[2]);
+    for (int a = 0; a < 3; a++) u[a] = (1 / len) * cr[a];
+    v[0] = w[1] * u[2] - w[2] * u[1]; v[1] = w[2] * u[0] - w[0] * u[2]; v[2] = w[0] * u[1] - w[1] * u[0];
+    for (int a = 0; a < 3; a++) {
+        double hor = c.focus_dist * vw * u[a], ver = c.focus_dist * vh * v[a];
+        double llc = c.lookfrom[a] - hor / 2 - ver / 2 - c.focus_dist * w[a];
+        out->origin[a] = (float)c.lookfrom[a];
+        out->llc_rel[a] = (float)(llc - c.lookfrom[a]);
+        out->horizontal[a] = (float)hor;
+        out->vertical[a] = (float)ver;
+        out->u[a] = (float)u[a];
+        out->v[a] = (float)v[a];
+    }
+    out->lens_radius = (float)(c.aperture / 2);
+}
+
+int shard_rows(int height, int tile_rows, int tile_first, int tile_step) {
+    if (tile_rows <= 0 || tile_step <= 0) return height;
+    int n_tiles = (height + tile_rows - 1) / tile_rows;
+    int rows = 0;
+    for (int t = tile_first; t < n_tiles; t += tile_step) {
+        int r0 = t * tile_rows, r1 = r0 + tile_rows;
+        rows += (r1 > height ? height : r1) - r0;
+    }
+    return rows;
+}
+
+int choose_lanes_per_pixel(long long pixels, int spp) {
+    // enough waves to fill 256 CUs several times over, decided from the whole frame (not from a
+    // shard) so that an image does not depend on how many GPUs render it
+    const long long want_waves = 16384;
+    int k = 1;
+    while (k < 64 && pixels * k / 64 < want_waves && 2 * k <= spp) k *= 2;
+    return k;
+}
+
+int validate_render(rt_context* ctx, const rt_render_params* p, rt::DRender* rp) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (!p || p->struct_size != sizeof(rt_render_params))
+        return fail(ctx, RT_ERR_INVALID, "rt_render_params: null or struct_size mismatch");
+    if (!ctx->has_scene) return fail(ctx, RT_ERR_NO_SCENE, "no scene uploaded");
+    if (!ctx->has_camera) return fail(ctx, RT_ERR_NO_CAMERA, "no camera set");
+    if (p->width < 2 || p->height < 2 || p->width > 65536 || p->height > 65536)
+        return fail(ctx, RT_ERR_INVALID, "width/height must be in [2, 65536]");
+    if (p->spp < 1 || p->sample_begin < 0 || p->max_depth < 0)
+        return fail(ctx, RT_ERR_INVALID, "spp >= 1, sample_begin >= 0, max_depth >= 0 required");
+    if ((long long)p->sample_begin + p->spp > 0x7fffffffLL)
+        return fail(ctx, RT_ERR_INVALID, "sample range overflows");
+    bool whole = p->tile_rows == 0 && p->tile_first == 0 && p->tile_step == 0;
+    if (!whole && (p->tile_rows < 1 || p->tile_step < 1 || p->tile_first < 0 || p->tile_first >= p->tile_step))
+        return fail(ctx, RT_ERR_INVALID, "tiles: tile_rows >= 1, 0 <= tile_first < tile_step required");
+    int k = p->lanes_per_pixel;
+    if (k == 0) k = choose_lanes_per_pixel((long long)p->width * p->height, p->spp);
+    if (k < 1 || k > 64 || (k & (k - 1)) != 0)
+        return fail(ctx, RT_ERR_INVALID, "lanes_per_pixel must be 0 or a power of two <= 64");
+    if (!(p->t_min >= 0.0f) || !std::isfinite(p->t_min)) return fail(ctx, RT_ERR_INVALID, "t_min must be >= 0");
+    rp->width = p->width; rp->height = p->height;
+    rp->spp = p->spp; rp->sample_begin = p->sample_begin; rp->max_depth = p->max_depth;
+    rp->seed_lo = (uint32_t)p->seed; rp->seed_hi = (uint32_t)(p->seed >> 32);
+    rp->tile_rows = whole ? p->height : p->tile_rows;
+    rp->tile_first = whole ? 0 : p->tile_first;
+    rp->tile_step = whole ? 1 : p->tile_step;
+    rp->rows = shard_rows(p->height, rp->tile_rows, rp->tile_first, rp->tile_step);
+    rp->t_min = p->t_min == 0.0f ? 0.001f : p->t_min;
+    rp->flags = p->flags;
+    rp->lanes_per_pixel = k;
+    rp->inv_wm1 = (float)(1.0 / (double)(p->width - 1));
+    rp->inv_hm1 = (float)(1.0 / (double)(p->height - 1));
+    return RT_OK;
+}
+
+int do_render(rt_context* ctx, const rt::DRender& rp, float4* out_dev) {
+    RT_HIP(ctx, hipMemsetAsync(ctx->counters, 0, rt::kNumCounters * sizeof(unsigned long long), ctx->stream));
+    RT_HIP(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
+    RT_HIP(ctx, rt::launch_render(ctx->scene, ctx->camera, rp, out_dev, ctx->counters, ctx->stream));
+    RT_HIP(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
+    ctx->timed = true;
+    ctx->last_k = rp.lanes_per_pixel;
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rt_version(void) { return "raytrace_amd 0.1 (gfx950)"; }
+
+int rt_create(int device, rt_context** out) {
+    if (!out) return RT_ERR_INVALID;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return RT_ERR_NO_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return RT_ERR_NO_DEVICE;
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return RT_ERR_NO_DEVICE;   // kernels are gfx950 only
+    rt_context* ctx = new (std::nothrow) rt_context;
+    if (!ctx) return RT_ERR_INVALID;
+    ctx->device = device;
+    DeviceGuard g(device);
+    if (hipMalloc((void**)&ctx->counters, rt::kNumCounters * sizeof(unsigned long long)) != hipSuccess ||
+        hipEventCreate(&ctx->ev_start) != hipSuccess || hipEventCreate(&ctx->ev_stop) != hipSuccess) {
+        rt_destroy(ctx);
+        return RT_ERR_HIP;
+    }
+    *out = ctx;
+    return RT_OK;
+}
+
+void rt_destroy(rt_context* ctx) {
+    if (!ctx) return;
+    DeviceGuard g(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    free_scene(ctx);
+    if (ctx->counters) (void)hipFree(ctx->counters);
+    if (ctx->staging) (void)hipFree(ctx->staging);
+    if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
+    if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
+    delete ctx;
+}
+
+int rt_set_stream(rt_context* ctx, void* hip_stream) {
+    if (!ctx) return RT_ERR_INVALID;
+    ctx->stream = static_cast<hipStream_t>(hip_stream);
+    return RT_OK;
+}
+
+const char* rt_last_error(rt_context* ctx) { return ctx ? ctx->error.c_str() : "null context"; }
+
+int rt_shard_rows(int32_t height, int32_t tile_rows, int32_t tile_first, int32_t tile_step) {
+    if (height < 0) return RT_ERR_INVALID;
+    bool whole = tile_rows == 0 && tile_first == 0 && tile_step == 0;
+    if (!whole && (tile_rows < 1 || tile_step < 1 || tile_first < 0 || tile_first >= tile_step)) return RT_ERR_INVALID;
+    return shard_rows(height, tile_rows, tile_first, tile_step);
+}
+
+int rt_upload_scene(rt_context* ctx, const rt_scene_desc* d) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (!d || d->struct_size != sizeof(rt_scene_desc))
+        return fail(ctx, RT_ERR_INVALID, "rt_scene_desc: null or struct_size mismatch");
+    if (d->n_prims < 0 || d->n_mats < 0 || d->n_tex < 0) return fail(ctx, RT_ERR_INVALID, "negative count");
+    if (d->n_prims > 0 && (!d->prim_type || !d->prim_geom || !d->prim_mat))
+        return fail(ctx, RT_ERR_INVALID, "primitive arrays missing");
+    if (d->n_mats > 0 && (!d->mat_type || !d->mat_param || !d->mat_tex))
+        return fail(ctx, RT_ERR_INVALID, "material arrays missing");
+    if (d->n_tex > 0 && (!d->tex_type || !d->tex_color || !d->tex_a || !d->tex_b || !d->tex_off))
+        return fail(ctx, RT_ERR_INVALID, "texture arrays missing");
+    if (d->accel < RT_ACCEL_AUTO || d->accel > RT_ACCEL_BVH) return fail(ctx, RT_ERR_INVALID, "unknown accel");
+    if (d->background != RT_BG_SKY && d->background != RT_BG_SOLID) return fail(ctx, RT_ERR_INVALID, "unknown background");
+    if (d->n_prims > (1 << 28)) return fail(ctx, RT_ERR_UNSUPPORTED, "more than 2^28 primitives");
+    const double wide_radius = d->wide_radius > 0 ? d->wide_radius : 64.0;
+
+    // textures
+    std::vector<rt::DTexture> texs((size_t)d->n_tex);
+    for (int i = 0; i < d->n_tex; i++) {
+        rt::DTexture& t = texs[i];
+        t = rt::DTexture{};
+        t.type = d->tex_type[i];
+        if (t.type == RT_TEX_SOLID) {
+            t.r = (float)d->tex_color[3 * i]; t.g = (float)d->tex_color[3 * i + 1]; t.bl = (float)d->tex_color[3 * i + 2];
+        } else if (t.type == RT_TEX_CHECKER) {
+            t.a = d->tex_a[i]; t.b = d->tex_b[i];
+            if (t.a < 0 || t.a >= d->n_tex || t.b < 0 || t.b >= d->n_tex)
+                return fail(ctx, RT_ERR_INVALID, "checker texture refers outside the texture array");
+        } else if (t.type == RT_TEX_IMAGE) {
+            t.a = d->tex_a[i]; t.b = d->tex_b[i];
+            int64_t off = d->tex_off[i];
+            if (t.a < 1 || t.b < 1 || t.a > 32768 || t.b > 32768 || off < 0 || !d->texels ||
+                (uint64_t)off + (uint64_t)t.a * t.b * 3 > d->texel_bytes || (uint64_t)off > 0xffffffffULL)
+                return fail(ctx, RT_ERR_INVALID, "image texture outside the texel blob");
+            t.off = (uint32_t)off;
+        } else {
+            return fail(ctx, RT_ERR_INVALID, "unknown texture type");
+        }
+    }
+    // checker nesting must end in a leaf texture within the kernel's 16-level walk
+    for (int i = 0; i < d->n_tex; i++) {
+        std::vector<int> todo{i};
+        for (int level = 0; !todo.empty(); level++) {
+            if (level > 8) return fail(ctx, RT_ERR_UNSUPPORTED, "checker textures nested deeper than 8 (or cyclic)");
+            std::vector<int> next;
+            for (int t : todo)
+                if (texs[t].type == RT_TEX_CHECKER) { next.push_back(texs[t].a); next.push_back(texs[t].b); }
+            todo.swap(next);
+        }
+    }
+
+    // materials
+    std::vector<rt::DMaterial> mats((size_t)d->n_mats);
+    for (int i = 0; i < d->n_mats; i++) {
+        rt::DMaterial& m = mats[i];
+        m = rt::DMaterial{};
+        m.type = d->mat_type[i];
+        if (m.type < RT_LAMBERTIAN || m.type > RT_LAMBERTIAN_BG) return fail(ctx, RT_ERR_INVALID, "unknown material type");
+        const double* p = d->mat_param + 5 * (size_t)i;
+        m.r = (float)p[0]; m.g = (float)p[1]; m.b = (float)p[2];
+        m.fuzz = (float)(p[3] < 1 ? p[3] : 1.0);           // material.h:40
+        m.ir = (float)p[4];
+        m.tex = d->mat_tex[i];
+        if (m.tex >= d->n_tex) return fail(ctx, RT_ERR_INVALID, "material refers outside the texture array");
+        if (m.tex < 0) m.tex = -1;
+        if ((m.type == RT_METAL || m.type == RT_DIELECTRIC) && m.tex >= 0) m.tex = -1;   // neither reads a texture
+        if (m.type == RT_DIELECTRIC && !(m.ir > 0.0f)) return fail(ctx, RT_ERR_INVALID, "dielectric needs ir > 0");
+    }
+
+    // primitives: ordinary spheres (BVH / scan), wide spheres and rects (always tested)
+    std::vector<double> sc_c, sc_r;          // ordinary spheres, input order
+    std::vector<int32_t> sc_obj, sc_mat;
+    std::vector<rt::DWide> wide;
+    std::vector<rt::DRect> rects;
+    for (int i = 0; i < d->n_prims; i++) {
+        const double* g = d->prim_geom + 6 * (size_t)i;
+        int mat = d->prim_mat[i];
+        if (mat < 0 || mat >= d->n_mats) return fail(ctx, RT_ERR_INVALID, "primitive refers outside the material array");
+        int type = d->prim_type[i];
+        if (type == RT_SPHERE) {
+            if (!finite3(g) || !std::isfinite(g[3]) || g[3] == 0.0) return fail(ctx, RT_ERR_INVALID, "sphere needs finite centre and non-zero radius");
+            if (std::fabs(g[3]) > wide_radius) {
+                rt::DWide w{};
+                w.cx = g[0]; w.cy = g[1]; w.cz = g[2]; w.r = g[3]; w.obj = i; w.mat = mat;
+                wide.push_back(w);
+            } else {
+                sc_c.insert(sc_c.end(), g, g + 3); sc_r.push_back(g[3]);
+                sc_obj.push_back(i); sc_mat.push_back(mat);
+            }
+        } else if (type == RT_XY_RECT || type == RT_XZ_RECT || type == RT_YZ_RECT) {
+            for (int a = 0; a < 5; a++) if (!std::isfinite(g[a])) return fail(ctx, RT_ERR_INVALID, "rect needs finite bounds");
+            rt::DRect r{};
+            r.a0 = (float)g[0]; r.a1 = (float)g[1]; r.b0 = (float)g[2]; r.b1 = (float)g[3]; r.k = (float)g[4];
+            int ka = type == RT_XY_RECT ? 2 : (type == RT_XZ_RECT ? 1 : 0);
+            int aa = type == RT_YZ_RECT ? 1 : 0;
+            int ba = type == RT_XY_RECT ? 1 : 2;
+            r.axes = ka | (aa << 2) | (ba << 4);
+            r.obj = i; r.mat = mat;
+            rects.push_back(r);
+        } else {
+            return fail(ctx, RT_ERR_INVALID, "unknown primitive type");
+        }
+    }
+    const int64_t ns = (int64_t)sc_r.size();
+
+    bool use_bvh = d->accel == RT_ACCEL_BVH || (d->accel == RT_ACCEL_AUTO && ns > 32);
+    rt::BvhResult bvh;
+    std::vector<int32_t> order((size_t)ns);
+    for (int64_t i = 0; i < ns; i++) order[i] = (int32_t)i;
+    if (use_bvh) {
+        bvh = rt::build_bvh(sc_c.data(), sc_r.data(), ns, rt::kMaxStack - 4);
+        if (bvh.depth > rt::kMaxStack - 2) return fail(ctx, RT_ERR_UNSUPPORTED, "BVH deeper than the traversal stack");
+        order = bvh.order;
+    }
+    std::vector<float4> sph((size_t)ns);
+    std::vector<double4> sph64((size_t)ns);
+    std::vector<int2> info((size_t)ns);
+    for (int64_t k = 0; k < ns; k++) {
+        int32_t i = order[k];
+        sph[k] = make_float4((float)sc_c[3 * i], (float)sc_c[3 * i + 1], (float)sc_c[3 * i + 2], (float)std::fabs(sc_r[i]));
+        sph64[k] = make_double4(sc_c[3 * i], sc_c[3 * i + 1], sc_c[3 * i + 2], sc_r[i]);
+        info[k] = make_int2(sc_obj[i], sc_mat[i]);
+    }
+
+    DeviceGuard g(ctx->device);
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    free_scene(ctx);
+    rt::DScene s{};
+    int rc;
+    std::vector<float4> nodes4(bvh.nodes.size() / 4);
+    if (!nodes4.empty()) std::memcpy(nodes4.data(), bvh.nodes.data(), bvh.nodes.size() * sizeof(float));
+    std::vector<uint8_t> texels;
+    if (d->texel_bytes && d->texels) texels.assign(d->texels, d->texels + d->texel_bytes);
+    if ((rc = upload(ctx, sph, &s.sph)) || (rc = upload(ctx, sph64, &s.sph64)) || (rc = upload(ctx, info, &s.sph_info)) ||
+        (rc = upload(ctx, nodes4, &s.nodes)) || (rc = upload(ctx, wide, &s.wide)) || (rc = upload(ctx, rects, &s.rects)) ||
+        (rc = upload(ctx, mats, &s.mats)) || (rc = upload(ctx, texs, &s.texs)) || (rc = upload(ctx, texels, &s.texels))) {
+        std::string keep = ctx->error;
+        free_scene(ctx);
+        ctx->error = keep;
+        return rc;
+    }
+    s.n_sph = (int)ns;
+    s.root = use_bvh ? bvh.root : rt::kNoBvh;
+    s.bvh_depth = bvh.depth;
+    s.use_bvh = use_bvh ? 1 : 0;
+    s.n_wide = (int)wide.size();
+    s.n_rects = (int)rects.size();
+    s.background = d->background;
+    for (int a = 0; a < 3; a++) s.bg[a] = d->bg_color[a];
+    ctx->scene = s;
+    ctx->accel_used = use_bvh ? RT_ACCEL_BVH : RT_ACCEL_LIST;
+    ctx->bvh_nodes = (int)(bvh.nodes.size() / 16);
+    ctx->bvh_depth = bvh.depth;
+    ctx->has_scene = true;
+    return RT_OK;
+}
+
+int rt_set_camera(rt_context* ctx, const rt_camera_desc* c) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (!c) return fail(ctx, RT_ERR_INVALID, "null camera");
+    if (!finite3(c->lookfrom) || !finite3(c->lookat) || !finite3(c->vup) || !(c->vfov > 0 && c->vfov < 180) ||
+        !(c->aspect > 0) || !(c->aperture >= 0) || !std::isfinite(c->focus_dist))
+        return fail(ctx, RT_ERR_INVALID, "camera: finite vectors, 0 < vfov < 180, aspect > 0, aperture >= 0 required");
+    rt::DCamera cam{};
+    build_camera(*c, &cam);
+    for (int a = 0; a < 3; a++)
+        if (!std::isfinite(cam.u[a]) || !std::isfinite(cam.v[a]))
+            return fail(ctx, RT_ERR_INVALID, "camera: lookfrom == lookat or vup parallel to the view direction");
+    ctx->camera = cam;
+    ctx->has_camera = true;
+    return RT_OK;
+}
+
+int rt_render(rt_context* ctx, const rt_render_params* params, float* rgba_device) {
+    rt::DRender rp{};
+    int rc = validate_render(ctx, params, &rp);
+    if (rc) return rc;
+    if (!rgba_device) return fail(ctx, RT_ERR_INVALID, "null output");
+    DeviceGuard g(ctx->device);
+    return do_render(ctx, rp, reinterpret_cast<float4*>(rgba_device));
+}
+
+int rt_render_host(rt_context* ctx, const rt_render_params* params, float* rgba_host) {
+    rt::DRender rp{};
+    int rc = validate_render(ctx, params, &rp);
+    if (rc) return rc;
+    if (!rgba_host) return fail(ctx, RT_ERR_INVALID, "null output");
+    DeviceGuard g(ctx->device);
+    size_t bytes = (size_t)rp.rows * rp.width * sizeof(float4);
+    if (bytes > ctx->staging_bytes) {
+        if (ctx->staging) (void)hipFree(ctx->staging);
+        ctx->staging = nullptr; ctx->staging_bytes = 0;
+        RT_HIP(ctx, hipMalloc((void**)&ctx->staging, bytes));
+        ctx->staging_bytes = bytes;
+    }
+    if ((rc = do_render(ctx, rp, ctx->staging))) return rc;
+    RT_HIP(ctx, hipMemcpyAsync(rgba_host, ctx->staging, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int rt_trace_primary(rt_context* ctx, const float* rays_host, int32_t n, float t_min, rt_hit* hits_host) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (!ctx->has_scene) return fail(ctx, RT_ERR_NO_SCENE, "no scene uploaded");
+    if (n < 0 || (n > 0 && (!rays_host || !hits_host))) return fail(ctx, RT_ERR_INVALID, "bad ray arrays");
+    if (!(t_min >= 0.0f)) return fail(ctx, RT_ERR_INVALID, "t_min must be >= 0");
+    if (n == 0) return RT_OK;
+    static_assert(sizeof(rt_hit) == sizeof(rt::Hit), "rt_hit layout");
+    DeviceGuard g(ctx->device);
+    float* d_rays = nullptr;
+    rt::Hit* d_hits = nullptr;
+    RT_HIP(ctx, hipMalloc((void**)&d_rays, (size_t)n * 6 * sizeof(float)));
+    hipError_t e = hipMalloc((void**)&d_hits, (size_t)n * sizeof(rt::Hit));
+    if (e == hipSuccess) e = hipMemcpyAsync(d_rays, rays_host, (size_t)n * 6 * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = rt::launch_trace(ctx->scene, d_rays, n, t_min == 0.0f ? 0.001f : t_min, 0u, d_hits, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(hits_host, d_hits, (size_t)n * sizeof(rt::Hit), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_rays);
+    if (d_hits) (void)hipFree(d_hits);
+    if (e != hipSuccess) return fail(ctx, RT_ERR_HIP, std::string("rt_trace_primary: ") + hipGetErrorString(e));
+    return RT_OK;
+}
+
+int rt_quantize(rt_context* ctx, const float* rgba_device, int64_t n_pixels, int32_t spp, uint8_t* rgb8_device) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (n_pixels < 0 || spp < 1 || (n_pixels > 0 && (!rgba_device || !rgb8_device)))
+        return fail(ctx, RT_ERR_INVALID, "rt_quantize: bad arguments");
+    DeviceGuard g(ctx->device);
+    RT_HIP(ctx, rt::launch_quantize(reinterpret_cast<const float4*>(rgba_device), n_pixels, spp, rgb8_device, ctx->stream));
+    return RT_OK;
+}
+
+int rt_get_stats(rt_context* ctx, rt_stats* out) {
+    if (!ctx || !out) return RT_ERR_INVALID;
+    DeviceGuard g(ctx->device);
+    std::memset(out, 0, sizeof(*out));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    unsigned long long c[rt::kNumCounters];
+    RT_HIP(ctx, hipMemcpy(c, ctx->counters, sizeof(c), hipMemcpyDeviceToHost));
+    out->rays = c[0]; out->samples = c[1];
+    out->box_tests = c[2]; out->sphere_tests = c[3]; out->sphere_hits = c[4];
+    out->rect_tests = c[5]; out->wide_tests = c[6]; out->shades = c[7];
+    if (ctx->timed) RT_HIP(ctx, hipEventElapsedTime(&out->kernel_ms, ctx->ev_start, ctx->ev_stop));
+    out->lanes_per_pixel = ctx->last_k;
+    out->accel = ctx->accel_used;
+    out->bvh_nodes = ctx->bvh_nodes;
+    out->bvh_depth = ctx->bvh_depth;
+    return RT_OK;
+}
+
+}  // extern "C"

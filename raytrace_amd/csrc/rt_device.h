@@ -1,0 +1,110 @@
+// Device-side records of the flattened scene (all in HBM) and the launch interface between
+// rt_api.cpp (host) and rt_kernels.hip (gfx950 kernels).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rt {
+
+// ---- scene records ----------------------------------------------------------------------
+
+// Ordinary sphere, single precision, in BVH leaf order: (cx, cy, cz, r).            16 B
+// The same sphere in double for the polish of the winning hit: (cx, cy, cz, r).     32 B
+// Its list position and material: (obj, mat).                                        8 B
+
+struct DWide {            // sphere too large for single precision; always tested, in double
+    double cx, cy, cz, r;
+    int obj, mat, pad0, pad1;
+};
+
+struct DRect {            // cuda/rect.h: plane axis `ka` at k, in-plane axes (aa, ba)
+    float a0, a1, b0, b1;
+    float k;
+    int axes;             // ka | aa << 2 | ba << 4
+    int obj, mat;
+};
+
+struct DMaterial {        // tagged union: material.h:15-92, cuda/material.h:33-47,103-119
+    int type, tex;
+    float r, g, b;        // albedo / emitted colour when tex < 0
+    float fuzz, ir, pad;
+};
+
+struct DTexture {         // tagged union: cuda/texture.h:17-78
+    int type;
+    int a, b;             // checker: even, odd texture | image: width, height
+    uint32_t off;         // image: byte offset into the texel blob
+    float r, g, bl, pad;  // solid colour
+};
+
+// BVH2 node, 64 B = four float4 loads.  Both children's boxes live in the parent so one
+// fetch decides both.  child >= 0: inner node index; child < 0: leaf, ~child = first << 2 |
+// (count - 1) into the leaf-ordered sphere arrays.
+//   q0 = (lmin.x lmin.y lmin.z lmax.x)  q1 = (lmax.y lmax.z rmin.x rmin.y)
+//   q2 = (rmin.z rmax.x rmax.y rmax.z)  q3 = (left, right, -, -) as int bits
+struct DScene {
+    const float4* sph;
+    const double4* sph64;
+    const int2* sph_info;
+    int n_sph;
+    const float4* nodes;
+    int root;             // inner index, leaf code, or kNoBvh
+    int bvh_depth;
+    int use_bvh;          // 0: scan all ordinary spheres in order
+    const DWide* wide;
+    int n_wide;
+    const DRect* rects;
+    int n_rects;
+    const DMaterial* mats;
+    const DTexture* texs;
+    const uint8_t* texels;
+    int background;
+    float bg[3];
+};
+
+struct DCamera {          // camera.h:8-16 after the constructor, single precision
+    float origin[3];
+    float llc_rel[3];     // lower_left_corner - origin, subtracted in double on the host
+    float horizontal[3];
+    float vertical[3];
+    float u[3], v[3];
+    float lens_radius;
+};
+
+struct DRender {
+    int width, height;
+    int spp, sample_begin, max_depth;
+    uint32_t seed_lo, seed_hi;
+    int tile_rows, tile_first, tile_step;   // normalised: tile_rows >= 1, tile_step >= 1
+    int rows;                               // rows this launch renders
+    float t_min;
+    uint32_t flags;
+    int lanes_per_pixel;                    // K: power of two, 1..64
+    float inv_wm1, inv_hm1;                 // 1/(W-1), 1/(H-1)  (main.cc:117-118)
+};
+
+// counters[0] rays, [1] samples, [2] box tests, [3] sphere tests, [4] sphere hits,
+// [5] rect tests, [6] wide tests, [7] shades
+constexpr int kNumCounters = 8;
+constexpr int kNoBvh = 0x7fffffff;
+constexpr int kMaxStack = 48;               // deepest BVH the traversal stack holds
+
+struct Hit {              // rt_hit of include/rt.h, device side (same layout)
+    int id;
+    float t;
+    float p[3];
+    float n[3];
+    int front;
+    float u, v;
+};
+
+// launchers (rt_kernels.hip)
+hipError_t launch_render(const DScene& sc, const DCamera& cam, const DRender& rp, float4* out,
+                         unsigned long long* counters, hipStream_t stream);
+hipError_t launch_trace(const DScene& sc, const float* rays, int n, float t_min, uint32_t flags,
+                        Hit* out, hipStream_t stream);
+hipError_t launch_quantize(const float4* rgba, long long n_pixels, int spp, uint8_t* rgb8,
+                           hipStream_t stream);
+
+}  // namespace rt

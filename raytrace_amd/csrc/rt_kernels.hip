@@ -1,0 +1,653 @@
+// gfx950 kernels of the per-pixel render path: camera ray -> closest hit -> scatter ->
+// accumulate (main.cc:10-35,111-126), written for 64-wide wavefronts.
+//
+// Work decomposition: one lane owns (pixel, contiguous slice of that pixel's samples) and runs
+// a flattened path state machine: every trip of the lane loop traces ONE ray for every live
+// lane, whichever sample or bounce that lane is at, so a lane whose path ended starts its next
+// sample in the very next trip instead of idling until the wave's longest path ends.  K lanes
+// (lanes_per_pixel) share a pixel; their partial sums are combined in lane order by shuffles,
+// so an image is a pure function of (scene, camera, params) whatever the GPU count.
+//
+// Numerics: single precision everywhere except (a) spheres flagged "wide" (radius above
+// rt_scene_desc.wide_radius: the r = 1000 ground of main.cc:42), whose quadratic cancels
+// catastrophically in float and is solved in double exactly as sphere.h:23-41 writes it, and
+// (b) a double-precision Newton polish of the winning ordinary sphere's root, so that hit
+// distance and normal agree with the double-precision reference to float rounding.
+#include "rt_device.h"
+#include "rt_philox.h"
+
+namespace rt {
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr float kInf = __builtin_huge_valf();
+
+struct V3 { float x, y, z; };
+__device__ __forceinline__ V3 mk(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ V3 ld3(const float* p) { return mk(p[0], p[1], p[2]); }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 operator*(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ V3 operator*(float s, V3 a) { return mk(s * a.x, s * a.y, s * a.z); }
+__device__ __forceinline__ V3 operator-(V3 a) { return mk(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ float dot(V3 a, V3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+// a + s*b
+__device__ __forceinline__ V3 madd(V3 a, float s, V3 b) { return mk(fmaf(s, b.x, a.x), fmaf(s, b.y, a.y), fmaf(s, b.z, a.z)); }
+__device__ __forceinline__ float comp(V3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+
+struct Counters { unsigned box, sph, sph_hit, rect, wide, shade; };
+
+// ---- closest hit ---------------------------------------------------------------------------
+
+struct Cand {
+    float tn;     // distance along the unit direction (= t * |d|)
+    double td;    // parametric t in double, for wide spheres
+    int kind;     // -1 none, 0 ordinary sphere, 1 wide sphere, 2 rect
+    int idx;      // index into the kind's array
+    int obj;      // list position: exact ties go to the later object (sceneobject_list.h:31-36
+                  // with the inclusive range test of sphere.h:35)
+};
+
+__device__ __forceinline__ bool better(float tn, int obj, const Cand& b) {
+    return tn < b.tn || (tn == b.tn && obj > b.obj);
+}
+
+// sphere.h:18-41 in double, unnormalised direction, parametric t.
+__device__ __forceinline__ bool wide_hit(const DWide& w, V3 o, V3 d, double t_min, double t_max, double& t_out) {
+    double ocx = (double)o.x - w.cx, ocy = (double)o.y - w.cy, ocz = (double)o.z - w.cz;
+    double dx = d.x, dy = d.y, dz = d.z;
+    double a = dx * dx + dy * dy + dz * dz;
+    double b = 2.0 * (ocx * dx + ocy * dy + ocz * dz);
+    double c = (ocx * ocx + ocy * ocy + ocz * ocz) - w.r * w.r;
+    double disc = b * b - 4.0 * a * c;
+    if (disc < 0.0) return false;
+    double sq = sqrt(disc);
+    double root = (-b - sq) / (2.0 * a);
+    if (root < t_min || root > t_max) {
+        root = (-b + sq) / (2.0 * a);
+        if (root < t_min || root > t_max) return false;
+    }
+    t_out = root;
+    return true;
+}
+
+// Ordinary sphere against a unit direction: distance of the centre's foot point along the ray
+// (tca), squared distance of the centre from the ray line (l2), half chord (thc).  Works on
+// differences of nearby numbers only, so it stays accurate where b*b - 4ac cancels.
+__device__ __forceinline__ bool sphere_test(float4 s, V3 o, V3 dh, float tn_min, float tn_max, float& tn_out) {
+    V3 L = mk(s.x - o.x, s.y - o.y, s.z - o.z);
+    float tca = dot(L, dh);
+    V3 l = madd(L, -tca, dh);
+    float l2 = dot(l, l);
+    float r2 = s.w * s.w;
+    if (!(l2 <= r2)) return false;
+    float thc = sqrtf(r2 - l2);
+    float root = tca - thc;
+    if (!(root >= tn_min && root <= tn_max)) {
+        root = tca + thc;
+        if (!(root >= tn_min && root <= tn_max)) return false;
+    }
+    tn_out = root;
+    return true;
+}
+
+// cuda/rect.h:29-52 (xy), 75-99 (xz), 122-146 (yz); parametric t.  A ray parallel to the plane
+// never hits.
+__device__ __forceinline__ bool rect_test(const DRect& r, V3 o, V3 d, float t_min, float t_max, float& t_out) {
+    int ka = r.axes & 3, aa = (r.axes >> 2) & 3, ba = (r.axes >> 4) & 3;
+    float t = (r.k - comp(o, ka)) / comp(d, ka);
+    if (!(t >= t_min && t <= t_max)) return false;
+    float av = fmaf(t, comp(d, aa), comp(o, aa));
+    float bv = fmaf(t, comp(d, ba), comp(o, ba));
+    if (!(av >= r.a0 && av <= r.a1 && bv >= r.b0 && bv <= r.b1)) return false;
+    t_out = t;
+    return true;
+}
+
+// Slab test (cuda/bounding_box.h:18-29) against [tn_min, tn_max]; boxes are padded on the host
+// and the exit distance is widened by a few ulps, so rounding can only add visits.
+__device__ __forceinline__ bool box_test(float bx0, float by0, float bz0, float bx1, float by1, float bz1,
+                                         V3 o, V3 idir, float tn_min, float tn_max, float& t_enter) {
+    float tx0 = (bx0 - o.x) * idir.x, tx1 = (bx1 - o.x) * idir.x;
+    float ty0 = (by0 - o.y) * idir.y, ty1 = (by1 - o.y) * idir.y;
+    float tz0 = (bz0 - o.z) * idir.z, tz1 = (bz1 - o.z) * idir.z;
+    float tnear = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), tn_min));
+    float tfar = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), tn_max));
+    t_enter = tnear;
+    return tnear <= tfar * 1.0000005f;
+}
+
+template <bool COUNT>
+__device__ __forceinline__ void leaf_spheres(const DScene& sc, int first, int count, V3 o, V3 dh,
+                                             float tn_min, Cand& best, Counters& cn) {
+    for (int i = first; i < first + count; i++) {
+        float4 s = sc.sph[i];
+        float tn;
+        if (COUNT) cn.sph++;
+        if (sphere_test(s, o, dh, tn_min, best.tn, tn)) {
+            int obj = sc.sph_info[i].x;
+            if (COUNT) cn.sph_hit++;
+            if (better(tn, obj, best)) { best.tn = tn; best.kind = 0; best.idx = i; best.obj = obj; }
+        }
+    }
+}
+
+// Closest hit over the whole scene.  `stack` is this lane's column of the workgroup's LDS
+// traversal stack (entry e at stack[e * kBlock]).
+template <bool COUNT>
+__device__ __forceinline__ Cand closest_hit(const DScene& sc, V3 o, V3 d, float t_min, int* stack, Counters& cn) {
+    Cand best;
+    best.tn = kInf; best.td = 0.0; best.kind = -1; best.idx = -1; best.obj = -1;
+    float len2 = dot(d, d);
+    float len = sqrtf(len2);
+    float inv_len = 1.0f / len;
+    V3 dh = inv_len * d;
+    float tn_min = t_min * len;
+
+    // always-tested primitives: wide spheres (double) and rects
+    for (int i = 0; i < sc.n_wide; i++) {
+        const DWide w = sc.wide[i];
+        double t;
+        if (COUNT) cn.wide++;
+        // only wide spheres have been seen so far: compare in double, later object wins a tie
+        double tmax = best.kind < 0 ? (double)kInf : best.td;
+        if (wide_hit(w, o, d, (double)t_min, tmax, t) && (best.kind < 0 || t < best.td || w.obj > best.obj)) {
+            best.tn = (float)(t * (double)len); best.td = t; best.kind = 1; best.idx = i; best.obj = w.obj;
+        }
+    }
+    for (int i = 0; i < sc.n_rects; i++) {
+        const DRect r = sc.rects[i];
+        float t;
+        if (COUNT) cn.rect++;
+        if (rect_test(r, o, d, t_min, kInf, t)) {
+            float tn = t * len;
+            if (better(tn, r.obj, best)) { best.tn = tn; best.td = (double)t; best.kind = 2; best.idx = i; best.obj = r.obj; }
+        }
+    }
+
+    if (!sc.use_bvh) {
+        // sceneobject_list.h:26-39: every ordinary sphere, in list order
+        for (int i = 0; i < sc.n_sph; i++) {
+            float4 s = sc.sph[i];
+            float tn;
+            if (COUNT) cn.sph++;
+            if (sphere_test(s, o, dh, tn_min, best.tn, tn)) {
+                int obj = sc.sph_info[i].x;
+                if (COUNT) cn.sph_hit++;
+                if (better(tn, obj, best)) { best.tn = tn; best.kind = 0; best.idx = i; best.obj = obj; }
+            }
+        }
+        return best;
+    }
+
+    if (sc.root == kNoBvh) return best;
+    V3 idir = mk(1.0f / dh.x, 1.0f / dh.y, 1.0f / dh.z);
+    int sp = 0;
+    int cur = sc.root;
+    for (;;) {
+        if (cur >= 0) {
+            const float4* n = sc.nodes + 4 * (size_t)cur;
+            float4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
+            int left = __float_as_int(q3.x), right = __float_as_int(q3.y);
+            float tl, tr;
+            if (COUNT) cn.box += 2;
+            bool hl = box_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, idir, tn_min, best.tn, tl);
+            bool hr = box_test(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, idir, tn_min, best.tn, tr);
+            if (hl && hr) {
+                bool left_first = tl <= tr;
+                int near = left_first ? left : right;
+                int far = left_first ? right : left;
+                stack[sp * kBlock] = far;
+                sp++;
+                cur = near;
+                continue;
+            }
+            if (hl) { cur = left; continue; }
+            if (hr) { cur = right; continue; }
+        } else {
+            int code = ~cur;
+            leaf_spheres<COUNT>(sc, code >> 2, (code & 3) + 1, o, dh, tn_min, best, cn);
+        }
+        if (sp == 0) break;
+        sp--;
+        cur = stack[sp * kBlock];
+    }
+    return best;
+}
+
+// ---- hit record ------------------------------------------------------------------------------
+
+struct Rec {
+    V3 p, n;        // n faces against the ray (sceneobject.h:16-23)
+    float t;        // parametric
+    float u, v;
+    int front, mat, obj;
+};
+
+// cuda/sphere.h:20-26 on the unit outward normal
+__device__ __forceinline__ void sphere_uv(V3 on, float& u, float& v) {
+    const float pi = 3.14159265358979323846f;
+    float theta = acosf(fminf(fmaxf(-on.y, -1.0f), 1.0f));
+    float phi = atan2f(-on.z, on.x) + pi;
+    u = phi * (1.0f / (2.0f * pi));
+    v = theta * (1.0f / pi);
+}
+
+__device__ __forceinline__ void face(Rec& r, V3 d, V3 outward) {
+    r.front = dot(d, outward) < 0.0f;
+    r.n = r.front ? outward : -outward;
+}
+
+// Fill the record of the winning candidate.  Ordinary spheres: Newton steps on
+// f(t) = a t^2 + 2 hb t + c in double from the single-precision root (the correction itself is
+// a float division), then p and the normal from the polished t.
+__device__ __forceinline__ Rec make_record(const DScene& sc, const Cand& c, V3 o, V3 d, bool refine, bool want_uv) {
+    Rec r;
+    r.obj = c.obj;
+    r.u = 0.0f; r.v = 0.0f;
+    if (c.kind == 2) {
+        const DRect q = sc.rects[c.idx];
+        int ka = q.axes & 3, aa = (q.axes >> 2) & 3, ba = (q.axes >> 4) & 3;
+        float t = (float)c.td;
+        r.t = t;
+        r.p = madd(o, t, d);
+        r.u = (comp(r.p, aa) - q.a0) / (q.a1 - q.a0);
+        r.v = (comp(r.p, ba) - q.b0) / (q.b1 - q.b0);
+        face(r, d, mk(ka == 0 ? 1.0f : 0.0f, ka == 1 ? 1.0f : 0.0f, ka == 2 ? 1.0f : 0.0f));
+        r.mat = q.mat;
+        return r;
+    }
+    double cx, cy, cz, rad, t;
+    if (c.kind == 1) {
+        const DWide w = sc.wide[c.idx];
+        cx = w.cx; cy = w.cy; cz = w.cz; rad = w.r; t = c.td;
+        r.mat = w.mat;
+    } else {
+        float len = sqrtf(dot(d, d));
+        float tf = c.tn / len;
+        r.mat = sc.sph_info[c.idx].y;
+        if (!refine) {
+            float4 s = sc.sph[c.idx];
+            r.t = tf;
+            r.p = madd(o, tf, d);
+            V3 on = (1.0f / s.w) * mk(r.p.x - s.x, r.p.y - s.y, r.p.z - s.z);
+            face(r, d, on);
+            if (want_uv) sphere_uv(on, r.u, r.v);
+            return r;
+        }
+        double4 s = sc.sph64[c.idx];
+        cx = s.x; cy = s.y; cz = s.z; rad = s.w;
+        double ocx = (double)o.x - cx, ocy = (double)o.y - cy, ocz = (double)o.z - cz;
+        double dx = d.x, dy = d.y, dz = d.z;
+        double a = dx * dx + dy * dy + dz * dz;
+        double hb = ocx * dx + ocy * dy + ocz * dz;
+        double cc = (ocx * ocx + ocy * ocy + ocz * ocz) - rad * rad;
+        t = (double)tf;
+        for (int it = 0; it < 2; it++) {
+            double g = fma(a, t, hb);                 // f'(t) / 2
+            double f = fma(g + hb, t, cc);            // (a t + 2 hb) t + c
+            float fp = 2.0f * (float)g;
+            if (fp == 0.0f) break;
+            float corr = (float)f / fp;
+            t -= (double)corr;
+            if (fabsf(corr) <= 1e-5f * fabsf(tf)) break;
+        }
+    }
+    double px = fma(t, (double)d.x, (double)o.x), py = fma(t, (double)d.y, (double)o.y), pz = fma(t, (double)d.z, (double)o.z);
+    float inv_r = 1.0f / (float)rad;
+    double ir = (double)inv_r;
+    ir = ir * (2.0 - rad * ir);                       // one Newton step: 1/r to double accuracy
+    V3 on = mk((float)((px - cx) * ir), (float)((py - cy) * ir), (float)((pz - cz) * ir));
+    r.t = (float)t;
+    r.p = mk((float)px, (float)py, (float)pz);
+    face(r, d, on);
+    if (want_uv) sphere_uv(on, r.u, r.v);
+    return r;
+}
+
+// ---- textures (cuda/texture.h) --------------------------------------------------------------------
+
+__device__ __forceinline__ V3 texture_value(const DScene& sc, int tex, float u, float v, V3 p) {
+    for (int guard = 0; guard < 16; guard++) {
+        const DTexture t = sc.texs[tex];
+        if (t.type == 0) return mk(t.r, t.g, t.bl);
+        if (t.type == 1) {                             // cuda/texture.h:43-52
+            float sines = sinf(10.0f * p.x) * sinf(10.0f * p.y) * sinf(10.0f * p.z);
+            tex = sines < 0.0f ? t.b : t.a;
+            continue;
+        }
+        // cuda/texture.h:63-76 with the sampler state of cuda/main.cu:421-425 restated in
+        // arithmetic: normalised coordinates, wrap addressing, point filter on a 3W x H array
+        // of single bytes.
+        int W = t.a, H = t.b;
+        const uint8_t* img = sc.texels + t.off;
+        float vf = 1.0f - v;
+        uint32_t col = (uint32_t)(u * (float)W);
+        float yw = vf - floorf(vf);
+        int iy = (int)floorf(yw * (float)H);
+        iy = iy >= H ? H - 1 : iy;
+        float out[3];
+        float denom = 1.0f / (float)(3 * W);
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            float xn = (3.0f * (float)col + 0.5f + (float)c) * denom;
+            float xw = xn - floorf(xn);
+            int ix = (int)floorf(xw * (float)(3 * W));
+            ix = ix >= 3 * W ? 3 * W - 1 : ix;
+            out[c] = (float)img[(size_t)iy * (size_t)(3 * W) + ix] / 255.0f;
+        }
+        return mk(out[0], out[1], out[2]);
+    }
+    return mk(0.0f, 0.0f, 0.0f);
+}
+
+__device__ __forceinline__ V3 material_color(const DScene& sc, const DMaterial& m, const Rec& r) {
+    if (m.tex >= 0) return texture_value(sc, m.tex, r.u, r.v, r.p);
+    return mk(m.r, m.g, m.b);
+}
+
+// ---- random stream -----------------------------------------------------------------------------------
+
+struct Key { uint32_t seed_lo, seed_hi, pixel, sample; };
+
+__device__ __forceinline__ float u01(uint32_t w) { return (float)(w >> 8) * 5.9604644775390625e-08f; }  // 2^-24
+__device__ __forceinline__ float pm1(uint32_t w) { return fmaf(2.0f, u01(w), -1.0f); }                   // random_double(-1,1)
+
+// vec3.h:130-136.  Attempt i of a scatter segment reads words 0,1,2 of block i: the first draw
+// is z, then y, then x (argument evaluation order of the reference build, vec3.h:60).
+__device__ __forceinline__ V3 in_unit_sphere(const Key& k, uint32_t segment) {
+    for (uint32_t i = 0;; i++) {
+        uint4 w = philox4x32_10(k.pixel, k.sample, segment, i, k.seed_lo, k.seed_hi);
+        V3 p = mk(pm1(w.z), pm1(w.y), pm1(w.x));
+        if (!(dot(p, p) >= 1.0f) || i > 64) return p;
+    }
+}
+
+// ---- materials (material.h:15-92; emitters cuda/material.h:33-47,103-119) -------------------------------------
+
+// vec3.h:159
+__device__ __forceinline__ V3 reflect(V3 v, V3 n) { return madd(v, -2.0f * dot(v, n), n); }
+
+// Returns true when the path continues along (so, sd).  `emitted` is always written.
+__device__ __forceinline__ bool scatter(const DScene& sc, const DMaterial& m, V3 d, const Rec& r, const Key& k,
+                                        uint32_t segment, V3& att, V3& sd, V3& emitted) {
+    emitted = mk(0.0f, 0.0f, 0.0f);
+    switch (m.type) {
+    case 0: {                                          // lambertian, material.h:21-32
+        V3 s = in_unit_sphere(k, segment);
+        V3 uvec = (1.0f / sqrtf(dot(s, s))) * s;       // vec3.h:139
+        V3 dir = r.n + uvec;
+        const float thr = 1e-8f;                       // vec3.h:64-68
+        if (fabsf(dir.x) < thr && fabsf(dir.y) < thr && fabsf(dir.z) < thr) dir = r.n;
+        sd = dir;
+        att = material_color(sc, m, r);
+        return true;
+    }
+    case 1: {                                          // metal, material.h:42-47
+        V3 ud = (1.0f / sqrtf(dot(d, d))) * d;
+        V3 refl = reflect(ud, r.n);
+        if (m.fuzz > 0.0f) refl = madd(refl, m.fuzz, in_unit_sphere(k, segment));
+        sd = refl;
+        att = mk(m.r, m.g, m.b);
+        return dot(sd, r.n) > 0.0f;
+    }
+    case 2: {                                          // dielectric, material.h:58-91
+        att = mk(1.0f, 1.0f, 1.0f);
+        float ratio = r.front ? (1.0f / m.ir) : m.ir;
+        V3 ud = (1.0f / sqrtf(dot(d, d))) * d;
+        float cos_theta = fminf(dot(-ud, r.n), 1.0f);
+        float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+        bool tir = ratio * sin_theta > 1.0f;
+        float r0 = (1.0f - ratio) / (1.0f + ratio);
+        r0 = r0 * r0;
+        float x = 1.0f - cos_theta;
+        float x2 = x * x;
+        float refl_prob = r0 + (1.0f - r0) * (x2 * x2 * x);
+        uint4 w = philox4x32_10(k.pixel, k.sample, segment, 0u, k.seed_lo, k.seed_hi);
+        if (tir || refl_prob > u01(w.x)) {
+            sd = reflect(ud, r.n);
+        } else {                                       // vec3.h:163-169
+            V3 perp = ratio * madd(ud, cos_theta, r.n);
+            float par = -sqrtf(fabsf(1.0f - dot(perp, perp)));
+            sd = madd(perp, par, r.n);
+        }
+        return true;
+    }
+    default:                                           // diffuse_light, lambertian_bg
+        emitted = material_color(sc, m, r);
+        att = mk(0.0f, 0.0f, 0.0f);
+        sd = mk(0.0f, 0.0f, 0.0f);
+        return false;
+    }
+}
+
+// ---- camera (camera.h:40-45, main.cc:117-118) ---------------------------------------------------------------------
+
+// Segment 0 of a sample: draws 0,1 jitter the pixel (block 0 words 0,1); disk attempt 0 reads
+// block 0 words 2,3 (first draw y, second x, vec3.h:152), attempt a >= 1 reads words
+// 2*((a+1)&1) and +1 of block (a+1)>>1.
+__device__ __forceinline__ void camera_ray(const DCamera& cam, const DRender& rp, const Key& k, int i, int j, V3& o, V3& d) {
+    uint4 w = philox4x32_10(k.pixel, k.sample, 0u, 0u, k.seed_lo, k.seed_hi);
+    float s = ((float)i + u01(w.x)) * rp.inv_wm1;
+    float t = ((float)j + u01(w.y)) * rp.inv_hm1;
+    V3 offset = mk(0.0f, 0.0f, 0.0f);
+    if (cam.lens_radius != 0.0f) {
+        float py = pm1(w.z), px = pm1(w.w);
+        for (uint32_t a = 1; fmaf(px, px, py * py) >= 1.0f && a < 64; a++) {
+            if ((a & 1u) != 0u) {
+                w = philox4x32_10(k.pixel, k.sample, 0u, (a + 1u) >> 1, k.seed_lo, k.seed_hi);
+                py = pm1(w.x); px = pm1(w.y);
+            } else {
+                py = pm1(w.z); px = pm1(w.w);
+            }
+        }
+        float rx = cam.lens_radius * px, ry = cam.lens_radius * py;
+        offset = madd(rx * ld3(cam.u), ry, ld3(cam.v));
+    }
+    o = ld3(cam.origin) + offset;
+    d = madd(madd(ld3(cam.llc_rel), s, ld3(cam.horizontal)), t, ld3(cam.vertical)) - offset;
+}
+
+// main.cc:30-34
+__device__ __forceinline__ V3 background(const DScene& sc, V3 d) {
+    if (sc.background == 0) {
+        float y = d.y * (1.0f / sqrtf(dot(d, d)));
+        float t = 0.5f * (y + 1.0f);
+        return mk(fmaf(t, 0.5f, 1.0f - t), fmaf(t, 0.7f, 1.0f - t), fmaf(t, 1.0f, 1.0f - t));
+    }
+    return mk(sc.bg[0], sc.bg[1], sc.bg[2]);
+}
+
+__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// ---- render kernel ---------------------------------------------------------------------------------------------------
+
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void render_kernel(DScene sc, DCamera cam, DRender rp, float4* __restrict__ out,
+                                                        unsigned long long* __restrict__ counters) {
+    __shared__ int s_stack[kMaxStack * kBlock];
+    int* stack = s_stack + threadIdx.x;
+
+    const int lane = threadIdx.x & 63;
+    const int K = rp.lanes_per_pixel;
+    const int P = 64 / K;                       // pixels per wave
+    const int TW = P < 8 ? P : 8, TH = P / TW;  // wave tile
+    const int tiles_x = (rp.width + TW - 1) / TW;
+    const int tiles_y = (rp.rows + TH - 1) / TH;
+    const long long wave_id = (long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    const bool wave_ok = wave_id < (long long)tiles_x * tiles_y;
+    const int tile_x = (int)(wave_id % tiles_x), tile_y = (int)(wave_id / tiles_x);
+    const int pix = lane & (P - 1), chunk = lane / P;
+    const int x = tile_x * TW + (pix % TW);
+    const int ly = tile_y * TH + (pix / TW);    // row inside this shard's packed rows
+    const int j = (rp.tile_first + (ly / rp.tile_rows) * rp.tile_step) * rp.tile_rows + (ly % rp.tile_rows);
+    const bool valid = wave_ok && x < rp.width && ly < rp.rows && j < rp.height;
+
+    const int s_begin = rp.sample_begin + (int)(((long long)rp.spp * chunk) / K);
+    const int s_end = rp.sample_begin + (int)(((long long)rp.spp * (chunk + 1)) / K);
+
+    Key key;
+    key.seed_lo = rp.seed_lo; key.seed_hi = rp.seed_hi;
+    key.pixel = (uint32_t)(j * rp.width + x);
+    key.sample = (uint32_t)s_begin;
+
+    V3 acc = mk(0.0f, 0.0f, 0.0f);
+    unsigned nrays = 0, nsamples = 0;
+    Counters cn = {0, 0, 0, 0, 0, 0};
+    const bool refine = (rp.flags & 2u) == 0u;
+
+    int s = s_begin;
+    bool alive = valid && s < s_end && rp.max_depth > 0;
+    bool fresh = true;
+    V3 o = mk(0, 0, 0), d = mk(0, 0, 1), T = mk(1, 1, 1);
+    int depth = 0;
+    while (alive) {
+        if (fresh) {
+            key.sample = (uint32_t)s;
+            camera_ray(cam, rp, key, x, j, o, d);
+            T = mk(1.0f, 1.0f, 1.0f);
+            depth = 0;
+            fresh = false;
+            nsamples++;
+        }
+        Cand c = closest_hit<COUNT>(sc, o, d, rp.t_min, stack, cn);
+        nrays++;
+        depth++;
+        bool done;
+        if (c.kind < 0) {
+            acc = acc + T * background(sc, d);
+            done = true;
+        } else {
+            int mat = c.kind == 0 ? sc.sph_info[c.idx].y : (c.kind == 1 ? sc.wide[c.idx].mat : sc.rects[c.idx].mat);
+            const DMaterial m = sc.mats[mat];
+            Rec r = make_record(sc, c, o, d, refine, m.tex >= 0);
+            V3 att, sd, em;
+            if (COUNT) cn.shade++;
+            bool cont = scatter(sc, m, d, r, key, (uint32_t)depth, att, sd, em);
+            acc = acc + T * em;
+            T = T * att;
+            o = r.p;
+            d = sd;
+            done = !cont || depth >= rp.max_depth;     // main.cc:13-14: the limit ends in black
+        }
+        if (done) {
+            s++;
+            fresh = true;
+            alive = s < s_end;
+        }
+    }
+
+    // combine the K slices of each pixel in lane order, then one float4 store per pixel
+    V3 total = acc;
+    for (int cidx = 1; cidx < K; cidx++) {
+        int src = pix + cidx * P;
+        total.x += __shfl(acc.x, src, 64);
+        total.y += __shfl(acc.y, src, 64);
+        total.z += __shfl(acc.z, src, 64);
+    }
+    if (valid && chunk == 0) {
+        float a = (float)rp.spp;
+        if (rp.flags & 1u) {
+            float inv = 1.0f / a;
+            total = inv * total;
+        }
+        out[(size_t)ly * rp.width + x] = make_float4(total.x, total.y, total.z, a);
+    }
+
+    unsigned long long r_all = wave_sum(nrays), s_all = wave_sum(nsamples);
+    if (lane == 0 && r_all) {
+        atomicAdd(&counters[0], r_all);
+        atomicAdd(&counters[1], s_all);
+    }
+    if (COUNT) {
+        unsigned long long v[6] = {cn.box, cn.sph, cn.sph_hit, cn.rect, cn.wide, cn.shade};
+#pragma unroll
+        for (int q = 0; q < 6; q++) {
+            unsigned long long t = wave_sum(v[q]);
+            if (lane == 0 && t) atomicAdd(&counters[2 + q], t);
+        }
+    }
+}
+
+// ---- closest-hit kernel for explicit rays (parity hook) ------------------------------------------------------------------
+
+__global__ __launch_bounds__(kBlock) void trace_kernel(DScene sc, const float* __restrict__ rays, int n, float t_min,
+                                                       uint32_t flags, Hit* __restrict__ out) {
+    __shared__ int s_stack[kMaxStack * kBlock];
+    int* stack = s_stack + threadIdx.x;
+    int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    V3 o = mk(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]);
+    V3 d = mk(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]);
+    Counters cn = {0, 0, 0, 0, 0, 0};
+    Cand c = closest_hit<false>(sc, o, d, t_min, stack, cn);
+    Hit h;
+    if (c.kind < 0) {
+        h.id = -1; h.t = 0.0f; h.front = 0; h.u = 0.0f; h.v = 0.0f;
+        for (int a = 0; a < 3; a++) { h.p[a] = 0.0f; h.n[a] = 0.0f; }
+    } else {
+        Rec r = make_record(sc, c, o, d, (flags & 2u) == 0u, true);
+        h.id = r.obj; h.t = r.t; h.front = r.front; h.u = r.u; h.v = r.v;
+        h.p[0] = r.p.x; h.p[1] = r.p.y; h.p[2] = r.p.z;
+        h.n[0] = r.n.x; h.n[1] = r.n.y; h.n[2] = r.n.z;
+    }
+    out[i] = h;
+}
+
+// ---- write_color (color.h:9-26) ------------------------------------------------------------------------------------------------
+
+// The reference's `scale` is a float and the rest of the expression is double (color.h:17-23);
+// kept that way so the bytes equal the reference's for the same sums.
+__global__ __launch_bounds__(kBlock) void quantize_kernel(const float4* __restrict__ rgba, long long n, int spp,
+                                                          uint8_t* __restrict__ rgb8) {
+    long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    float scale = (float)(1.0 / (double)spp);
+    float4 c = rgba[i];
+    float v[3] = {c.x, c.y, c.z};
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        double g = sqrt((double)scale * (double)v[a]);
+        g = g < 0.0 ? 0.0 : (g > 0.999 ? 0.999 : g);
+        rgb8[3 * i + a] = (uint8_t)(int)(256.0 * g);
+    }
+}
+
+}  // namespace
+
+hipError_t launch_render(const DScene& sc, const DCamera& cam, const DRender& rp, float4* out,
+                         unsigned long long* counters, hipStream_t stream) {
+    const int K = rp.lanes_per_pixel;
+    const int P = 64 / K;
+    const int TW = P < 8 ? P : 8, TH = P / TW;
+    const long long tiles = (long long)((rp.width + TW - 1) / TW) * ((rp.rows + TH - 1) / TH);
+    const long long blocks = (tiles + (kBlock / 64) - 1) / (kBlock / 64);
+    if (blocks <= 0) return hipSuccess;
+    if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    if (rp.flags & 4u)
+        hipLaunchKernelGGL(render_kernel<true>, dim3((unsigned)blocks), dim3(kBlock), 0, stream, sc, cam, rp, out, counters);
+    else
+        hipLaunchKernelGGL(render_kernel<false>, dim3((unsigned)blocks), dim3(kBlock), 0, stream, sc, cam, rp, out, counters);
+    return hipGetLastError();
+}
+
+hipError_t launch_trace(const DScene& sc, const float* rays, int n, float t_min, uint32_t flags, Hit* out,
+                        hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(trace_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, sc, rays, n, t_min, flags, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_quantize(const float4* rgba, long long n_pixels, int spp, uint8_t* rgb8, hipStream_t stream) {
+    if (n_pixels <= 0) return hipSuccess;
+    hipLaunchKernelGGL(quantize_kernel, dim3((unsigned)((n_pixels + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream,
+                       rgba, n_pixels, spp, rgb8);
+    return hipGetLastError();
+}
+
+}  // namespace rt

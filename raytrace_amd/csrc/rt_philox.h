@@ -1,0 +1,34 @@
+// Philox4x32-10 (Salmon et al., SC'11), the counter-based generator behind every random draw of
+// the render path.  It replaces the reference's global rand() (utils.h:25) and the per-pixel
+// curandState of cuda/main.cu:281-291,340-348: a draw is a pure function of
+//     counter = (pixel, sample, segment, block)   key = (seed_lo, seed_hi)
+// where segment 0 holds a sample's camera draws and segment k >= 1 the scatter draws after the
+// k-th closest-hit query.  Uniforms are (word >> 8) * 2^-24, in [0,1) like random_double().
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rt {
+
+__host__ __device__ __forceinline__ uint4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                        uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1;
+        c3 = (uint32_t)p0;
+        c0 = n0;
+        c2 = n2;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    uint4 out;
+    out.x = c0; out.y = c1; out.z = c2; out.w = c3;
+    return out;
+}
+
+}  // namespace rt

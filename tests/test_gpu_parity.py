@@ -1,0 +1,137 @@
+"""GPU parity tests proper: the HIP kernels, driven through the C-ABI, against the golden vectors
+of the reference's compiled main.cc and against the CPU restatement on the same seeded inputs."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+CAM = dict(lookfrom=(6, 3, -13), lookat=(0, 0, 0), vup=(0, 1, 0), vfov=20.0, aspect=1.5,
+           aperture=0.1, focus_dist=10.0)
+
+
+@pytest.fixture(scope="module")
+def api():
+    from raytrace_amd import api as A
+    return A
+
+
+@pytest.fixture(scope="module", params=["bvh", "list"])
+def ctx(request, api, rtiow_flat):
+    c = api.Context(0)
+    c.upload_scene(rtiow_flat, accel=api.RT_ACCEL_BVH if request.param == "bvh" else api.RT_ACCEL_LIST)
+    c.set_camera(**CAM)
+    yield c
+    c.close()
+
+
+def test_primary_ray_hits_match_main_cc(ctx):
+    """north-star gate: hit object ids bit-exact, t and normals within 1e-5 relative."""
+    g = load_golden("primary_rays.npz")
+    hits = ctx.trace_primary(g["rays"], float(g["t_min"]))
+    # grazing rays in the fixture keep |b/r - 1| >= 1e-4 from a silhouette: decidable in float
+    assert np.min(g["graze_margin"][g["kind"] == 1]) > 5e-5
+    assert np.array_equal(hits["id"], g["id"])
+    hit = g["id"] >= 0
+    t_rel = np.abs(hits["t"][hit] - g["t"][hit]) / np.abs(g["t"][hit])
+    assert t_rel.max() <= 1e-5, t_rel.max()
+    assert np.abs(hits["n"][hit] - g["n"][hit]).max() <= 1e-5
+    assert np.array_equal(hits["front_face"][hit], g["front"][hit])
+    p_err = np.abs(hits["p"][hit] - g["p"][hit]).max(axis=1) / np.maximum(1.0, np.abs(g["p"][hit]).max(axis=1))
+    assert p_err.max() <= 1e-5
+
+
+@pytest.mark.parametrize("name,bound", [("image_120x80_16spp.npz", 1e-3), ("image_240x160_64spp.npz", 1e-3)])
+def test_keyed_stream_image_rmse(ctx, api, name, bound):
+    """Same Philox stream through the unmodified ray_color (golden) and through the kernels:
+    per-pixel RMSE of the mean radiance.  Independent seeds give 0.042 at 16 spp and 0.021 at
+    64 spp on this scene and the naive-float restatement of the path sits at 0.005; the kernels
+    measure 1.8e-4 and 1.3e-4 (paths that cross a float-vs-double branch threshold diverge, the
+    rest agree to rounding), so the stated bound is 1e-3."""
+    g = load_golden(name)
+    W, H, spp = int(g["W"]), int(g["H"]), int(g["spp"])
+    img = ctx.render_host(api.Context.params(W, H, spp, int(g["depth"]), int(g["seed"])))
+    st = ctx.stats()
+    assert np.all(img[..., 3] == spp)
+    mean = img[..., :3].astype(np.float64) / spp
+    rmse = np.sqrt(np.mean((mean - g["sums"] / spp) ** 2))
+    assert rmse <= bound, rmse
+    assert abs(st["rays"] - int(g["rays"])) / int(g["rays"]) < 0.002
+    assert st["samples"] == W * H * spp
+
+
+def test_statistical_agreement_1024spp(ctx, api):
+    """Converged image: 60x40 at 1024 spp, different seed than the golden render."""
+    g = load_golden("image_60x40_1024spp.npz")
+    img = ctx.render_host(api.Context.params(60, 40, 1024, 50, seed=4242))
+    mean = img[..., :3].astype(np.float64) / 1024
+    ref = g["sums"] / 1024
+    rmse = np.sqrt(np.mean((mean - ref) ** 2))
+    assert rmse < 0.012, rmse                      # two independent 1024-spp estimates: ~0.0075
+    assert abs(mean.mean() - ref.mean()) < 2e-3    # no brightness bias
+
+
+def test_determinism_tiles_and_sample_windows(ctx, api):
+    P = api.Context.params
+    full = ctx.render_host(P(120, 80, 16, 50, 1, lanes_per_pixel=4))
+    again = ctx.render_host(P(120, 80, 16, 50, 1, lanes_per_pixel=4))
+    assert np.array_equal(full, again)
+    # row tiles of 8 rows dealt to 3 shards reassemble to the same bits
+    out = np.zeros_like(full)
+    for g in range(3):
+        part = ctx.render_host(P(120, 80, 16, 50, 1, tiles=(8, g, 3), lanes_per_pixel=4))
+        rows = [r for t in range(g, 10, 3) for r in range(8 * t, 8 * t + 8)]
+        assert part.shape[0] == len(rows)
+        out[rows] = part
+    assert np.array_equal(out, full)
+    # two sample windows add up to the whole (float sums: tolerance)
+    a = ctx.render_host(P(120, 80, 8, 50, 1, sample_begin=0, lanes_per_pixel=4))
+    b = ctx.render_host(P(120, 80, 8, 50, 1, sample_begin=8, lanes_per_pixel=4))
+    np.testing.assert_allclose(a[..., :3] + b[..., :3], full[..., :3], rtol=2e-6, atol=1e-6)
+    # lanes_per_pixel only changes the order of the float sum
+    k1 = ctx.render_host(P(120, 80, 16, 50, 1, lanes_per_pixel=1))
+    np.testing.assert_allclose(k1[..., :3], full[..., :3], rtol=2e-6, atol=1e-6)
+    # the second sample window against the reference's own second window
+    h = load_golden("image_120x80_8spp_from8.npz")
+    rmse = np.sqrt(np.mean((b[..., :3] / 8 - h["sums"] / 8) ** 2))
+    assert rmse < 2e-3
+
+
+def test_depth_limits(ctx, api):
+    P = api.Context.params
+    black = ctx.render_host(P(64, 48, 4, 0, 9))
+    assert not black[..., :3].any() and ctx.stats()["rays"] == 0          # main.cc:13-14
+    one = ctx.render_host(P(64, 48, 4, 1, 9))
+    assert ctx.stats()["rays"] == 64 * 48 * 4                              # exactly the primary rays
+
+
+def test_quantize_matches_write_color(ctx, api, oracle):
+    import torch
+    g = load_golden("func_vectors.npz")
+    spp = int(g["wc_spp"])
+    sums = g["wc_in"].astype(np.float32)
+    rgba = torch.tensor(np.concatenate([sums, np.full((len(sums), 1), spp, np.float32)], axis=1), device="cuda")
+    rgb8 = torch.zeros((len(sums), 3), dtype=torch.uint8, device="cuda")
+    ctx.quantize(rgba.data_ptr(), len(sums), spp, rgb8.data_ptr())
+    torch.cuda.synchronize()
+    want = oracle.write_color(sums.astype(np.float64), spp)
+    assert np.array_equal(rgb8.cpu().numpy().astype(np.int32), want)
+
+
+def test_error_codes(api, rtiow_flat):
+    c = api.Context(0)
+    with pytest.raises(api.RtError) as e:
+        c.render_host(api.Context.params(64, 48, 1))
+    assert e.value.code == api.RT_ERR_NO_SCENE
+    c.upload_scene(rtiow_flat)
+    with pytest.raises(api.RtError) as e:
+        c.render_host(api.Context.params(64, 48, 1))
+    assert e.value.code == api.RT_ERR_NO_CAMERA
+    c.set_camera(**CAM)
+    with pytest.raises(api.RtError) as e:
+        c.render_host(api.Context.params(64, 48, 1, lanes_per_pixel=3))
+    assert e.value.code == api.RT_ERR_INVALID
+    with pytest.raises(api.RtError):
+        c.set_camera((0, 0, 0), (0, 0, 0), (0, 1, 0), 20, 1.5, 0, 10)
+    c.close()
