@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mrays/s and ms/frame of the RTIOW scene (the reference's default world,
+487 spheres) at 1920x1080, 100 samples per pixel, depth 50, on N MI355X of one node.
+
+A step is one frame.  With N > 1 (one process per GPU, launched by torch.distributed.run) the
+frame is split into interleaved 8-row tiles, each rank renders its tiles and the partial
+framebuffers are gathered on rank 0 over RCCL, inside the timed region.  A ray is one
+closest-hit query (main.cc:18), counted on the device.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+W, H, SPP, DEPTH, SEED, TILE_ROWS = 1920, 1080, 100, 50, 1, 8
+PEAK_FP32_TFLOPS = 157.3          # MI355X FP32 vector peak (256 CU x 128 lanes x 2 x 2.4 GHz)
+
+# algorithmic flops per unit of work, fixed constants: sphere test 25 (+24 when a root is
+# accepted), box test 24, rect test 6, scatter ~47 (80/15/5 % lambertian/metal/glass mix of
+# 45/50/70), miss (sky) 20, camera ray 40
+F_SPHERE, F_SPHERE_HIT, F_BOX, F_RECT, F_SHADE, F_MISS, F_CAMERA = 25, 24, 24, 6, 47, 20, 40
+
+
+def executed_flops(st):
+    misses = st["rays"] - st["shades"]
+    return ((st["sphere_tests"] + st["wide_tests"]) * F_SPHERE + st["sphere_hits"] * F_SPHERE_HIT +
+            st["box_tests"] * F_BOX + st["rect_tests"] * F_RECT + st["shades"] * F_SHADE +
+            misses * F_MISS + st["samples"] * F_CAMERA)
+
+
+def cpu_baseline():
+    """The reference's own main.cc (compiled into oracle/_ref) on one host core, on a bounded
+    sample of the same frame: every 4th pixel of every 4th row, 16 spp, glibc rand() like the
+    original binary.  Falls back to the C restatement when the compiled reference is absent."""
+    import numpy as np
+    from oracle.pyoracle import Oracle, Reference
+    from raytrace_amd import scene as S
+    aspect = float(np.float32(W / H))
+    sample = f"{W}x{H} frame, every 4th pixel of every 4th row, 16 spp, depth {DEPTH}, 1 thread"
+    if Reference.available():
+        ref = Reference()
+        ref.load_scene(S.rtiow_records())
+        ref.set_camera((6, 3, -13), (0, 0, 0), (0, 1, 0), 20.0, aspect, 0.1, 10.0)
+        t0 = time.perf_counter()
+        _, rays = ref.render_libc(W, H, 16, DEPTH, step=(4, 4))
+        dt = time.perf_counter() - t0
+        kind = "reference"
+    else:
+        orc = Oracle("f64")
+        flat = S.flatten(S.rtiow_scene())
+        cam = orc.camera((6, 3, -13), (0, 0, 0), (0, 1, 0), 20.0, aspect, 0.1, 10.0)
+        t0 = time.perf_counter()
+        _, rays = orc.render(flat, cam, W, H, 16, DEPTH, SEED, step=(4, 4), threads=1)
+        dt = time.perf_counter() - t0
+        kind = "port"
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": 1, "kind": kind, "sample": sample,
+            "seconds": dt, "rays": rays}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--accel", choices=["bvh", "list"], default="bvh")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from raytrace_amd import api, dist as rdist, scene as S
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    ctx = api.Context(local_rank)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.upload_scene(S.flatten(S.rtiow_scene()),
+                     accel=api.RT_ACCEL_BVH if args.accel == "bvh" else api.RT_ACCEL_LIST)
+    aspect = float(np.float32(W / H))
+    ctx.set_camera((6, 3, -13), (0, 0, 0), (0, 1, 0), 20.0, aspect, 0.1, 10.0)    # main.cc:100-106
+
+    tiles = (TILE_ROWS, rank, world) if world > 1 else (0, 0, 0)
+    max_rows = rdist.max_shard_rows(H, TILE_ROWS, world) if world > 1 else H
+    shard = torch.zeros((max_rows, W, 4), dtype=torch.float32, device="cuda")
+    params = api.Context.params(W, H, SPP, DEPTH, SEED, tiles=tiles)
+
+    def step(ev=None):
+        if ev:
+            ev[0].record()
+        ctx.render(params, shard.data_ptr())
+        if ev:
+            ev[1].record()
+        return rdist.gather_frame(shard, H, TILE_ROWS, rank, world)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+              for _ in range(args.steps)]
+    fence()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        frame = step(events[k])
+    fence()
+    dt = time.perf_counter() - t0
+
+    st = ctx.stats()                                  # last frame's device counters (all frames equal)
+    kernel_ms = sum(a.elapsed_time(b) for a, b in events) / max(args.steps, 1)
+    tot = torch.tensor([dt, float(st["rays"]), kernel_ms], dtype=torch.float64, device="cuda")
+    if world > 1:
+        mx = tot.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = tot.clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        dt, kernel_ms, rays_frame = float(mx[0]), float(mx[2]), float(sm[1])
+    else:
+        rays_frame = float(st["rays"])
+
+    # executed algorithmic flops of this rank's launch, from the counting build of the same kernel
+    cparams = api.Context.params(W, H, SPP, DEPTH, SEED, tiles=tiles, flags=api.RT_FLAG_COUNTERS)
+    ctx.render(cparams, shard.data_ptr())
+    cst = ctx.stats()
+    flops = executed_flops(cst)
+    n_prims = 487
+    brute = cst["rays"] * (n_prims * F_SPHERE + 70)
+
+    if rank == 0:
+        out = {
+            "metric": "Mrays/sec (whole node) + ms/frame 1080p@100spp",
+            "value": rays_frame * args.steps / dt / 1e6, "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: RTIOW random-spheres scene (the reference's default world, "
+                                   "487 spheres, g++ build) 1920x1080 @100spp depth 50",
+                       "accel": args.accel, "tile_rows": TILE_ROWS if world > 1 else None,
+                       "partition": f"row-tiles x{world}, RCCL gather to rank 0" if world > 1 else "single GPU",
+                       "rays_per_frame": rays_frame, "lanes_per_pixel": st["lanes_per_pixel"]},
+            "roofline": {"bound": "valu", "achieved": flops / (kernel_ms * 1e-3) / 1e12,
+                         "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                         "frac": flops / (kernel_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS, "traffic": None,
+                         "kernel": "render_kernel", "kernel_ms": kernel_ms,
+                         "flops_per_launch": flops,
+                         "bruteforce_equivalent_tflops": brute / (kernel_ms * 1e-3) / 1e12,
+                         "note": "FP32 VALU-bound path (no dense contraction, ~33 MB of HBM writes per frame); "
+                                 "achieved = executed algorithmic flops of rank 0's launch / its HIP-event time"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+            out["speedup_vs_cpu_1thread"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
