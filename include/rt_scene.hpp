@@ -1,0 +1,226 @@
+// rt_scene.hpp — header-only C++ facade over the C-ABI of rt.h.
+//
+// It keeps the reference's scene-authoring vocabulary (class names, constructor argument order
+// and meaning) so that host code written against the reference keeps compiling:
+//
+//   vec3 / point3 / color                         vec3.h:13-73
+//   sphere(center, radius, material)              sphere.h:13, cuda/sphere.h:16
+//   xy_rect / xz_rect / yz_rect(a0,a1,b0,b1,k,m)  cuda/rect.h:19,66,112
+//   sceneobject_list::add / clear                 sceneobject_list.h:16-21
+//   bvh_node(list)                                cuda/bvh.h:18
+//   lambertian / metal / dielectric               material.h:19,40,56
+//   lambertian_bg / diffuse_light                 cuda/material.h:37-38,107-109
+//   rgb_color / checker_texture / image_texture   cuda/texture.h:22,39-41,61
+//   camera(lookfrom, lookat, vup, vfov, aspect, aperture, focus_dist)   camera.h:19-20
+//
+// Objects only record what they were built from; `flat_scene` turns a sceneobject_list into the
+// arrays rt_upload_scene takes, and `renderer` owns an rt_context.  Nothing here computes pixels.
+#ifndef RT_SCENE_HPP
+#define RT_SCENE_HPP
+
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "rt.h"
+
+namespace rt_scene {
+
+using std::make_shared;
+using std::shared_ptr;
+
+struct vec3 {
+    double e[3];
+    vec3() : e{0, 0, 0} {}
+    vec3(double e0, double e1, double e2) : e{e0, e1, e2} {}
+    double x() const { return e[0]; }
+    double y() const { return e[1]; }
+    double z() const { return e[2]; }
+    double operator[](int i) const { return e[i]; }
+};
+using point3 = vec3;
+using color = vec3;
+
+// ---- textures ------------------------------------------------------------------------
+struct custom_texture { virtual ~custom_texture() = default; };
+struct rgb_color : custom_texture {
+    color color_value;
+    explicit rgb_color(color c) : color_value(c) {}
+    rgb_color(double r, double g, double b) : color_value(r, g, b) {}
+};
+struct checker_texture : custom_texture {
+    shared_ptr<custom_texture> even, odd;
+    checker_texture(shared_ptr<custom_texture> e, shared_ptr<custom_texture> o) : even(e), odd(o) {}
+    checker_texture(color c1, color c2) : even(make_shared<rgb_color>(c1)), odd(make_shared<rgb_color>(c2)) {}
+};
+// texels: RGB8 rows, top row first (what stbi_load(...,3) returns, cuda/main.cu:393)
+struct image_texture : custom_texture {
+    uint32_t texture_width, texture_height;
+    std::vector<uint8_t> texels;
+    image_texture(uint32_t w, uint32_t h, const uint8_t* rgb8) : texture_width(w), texture_height(h), texels(rgb8, rgb8 + (size_t)w * h * 3) {}
+};
+
+// ---- materials --------------------------------------------------------------------------
+struct material {
+    int type = RT_LAMBERTIAN;
+    color albedo{0, 0, 0};
+    double fuzz = 0, ir = 0;
+    shared_ptr<custom_texture> tex;
+    virtual ~material() = default;
+};
+struct lambertian : material {
+    explicit lambertian(const color& a) { type = RT_LAMBERTIAN; albedo = a; }
+    explicit lambertian(shared_ptr<custom_texture> a) { type = RT_LAMBERTIAN; tex = a; }
+};
+struct lambertian_bg : material {
+    explicit lambertian_bg(const color& a) { type = RT_LAMBERTIAN_BG; albedo = a; }
+    explicit lambertian_bg(shared_ptr<custom_texture> a) { type = RT_LAMBERTIAN_BG; tex = a; }
+};
+struct metal : material {
+    metal(const color& a, double f) { type = RT_METAL; albedo = a; fuzz = f < 1 ? f : 1; }   // material.h:40
+};
+struct dielectric : material {
+    explicit dielectric(double index_of_refraction) { type = RT_DIELECTRIC; albedo = color(1, 1, 1); ir = index_of_refraction; }
+};
+struct diffuse_light : material {
+    explicit diffuse_light(color c) { type = RT_DIFFUSE_LIGHT; albedo = c; }
+    explicit diffuse_light(shared_ptr<custom_texture> a) { type = RT_DIFFUSE_LIGHT; tex = a; }
+};
+
+// ---- objects ------------------------------------------------------------------------------
+struct sceneobject { virtual ~sceneobject() = default; };
+struct sphere : sceneobject {
+    point3 center; double radius; shared_ptr<material> mat_ptr;
+    sphere(point3 cen, double r, shared_ptr<material> m) : center(cen), radius(r), mat_ptr(m) {}
+};
+struct rect_base : sceneobject {
+    int kind; double a0, a1, b0, b1, k; shared_ptr<material> mat;
+    rect_base(int kind_, double a0_, double a1_, double b0_, double b1_, double k_, shared_ptr<material> m)
+        : kind(kind_), a0(a0_), a1(a1_), b0(b0_), b1(b1_), k(k_), mat(m) {}
+};
+struct xy_rect : rect_base { xy_rect(double x0, double x1, double y0, double y1, double k, shared_ptr<material> m) : rect_base(RT_XY_RECT, x0, x1, y0, y1, k, m) {} };
+struct xz_rect : rect_base { xz_rect(double x0, double x1, double z0, double z1, double k, shared_ptr<material> m) : rect_base(RT_XZ_RECT, x0, x1, z0, z1, k, m) {} };
+struct yz_rect : rect_base { yz_rect(double y0, double y1, double z0, double z1, double k, shared_ptr<material> m) : rect_base(RT_YZ_RECT, y0, y1, z0, z1, k, m) {} };
+
+struct sceneobject_list : sceneobject {
+    std::vector<shared_ptr<sceneobject>> objects;
+    sceneobject_list() {}
+    explicit sceneobject_list(shared_ptr<sceneobject> object) { add(object); }
+    void clear() { objects.clear(); }
+    void add(shared_ptr<sceneobject> object) { objects.push_back(object); }
+};
+// Grouping marker (cuda/bvh.h:18): the library builds one BVH over the whole flattened scene.
+struct bvh_node : sceneobject_list {
+    explicit bvh_node(const sceneobject_list& l) { objects = l.objects; }
+};
+
+struct camera {
+    rt_camera_desc d;
+    camera(point3 lookfrom, point3 lookat, vec3 vup, double vfov, double aspect_ratio, double aperture, double focus_dist) {
+        for (int a = 0; a < 3; a++) { d.lookfrom[a] = lookfrom[a]; d.lookat[a] = lookat[a]; d.vup[a] = vup[a]; }
+        d.vfov = vfov; d.aspect = aspect_ratio; d.aperture = aperture; d.focus_dist = focus_dist;
+    }
+};
+
+// ---- flattening ------------------------------------------------------------------------------
+struct flat_scene {
+    std::vector<int32_t> prim_type, prim_mat, mat_type, mat_tex, tex_type, tex_a, tex_b;
+    std::vector<double> prim_geom, mat_param, tex_color;
+    std::vector<int64_t> tex_off;
+    std::vector<uint8_t> texels;
+    std::map<const void*, int> mat_ids, tex_ids;
+
+    int tex_id(const shared_ptr<custom_texture>& t) {
+        auto it = tex_ids.find(t.get());
+        if (it != tex_ids.end()) return it->second;
+        int type, a = 0, b = 0; int64_t off = 0; color c;
+        if (auto s = dynamic_cast<rgb_color*>(t.get())) { type = RT_TEX_SOLID; c = s->color_value; }
+        else if (auto k = dynamic_cast<checker_texture*>(t.get())) { type = RT_TEX_CHECKER; a = tex_id(k->even); b = tex_id(k->odd); }
+        else if (auto im = dynamic_cast<image_texture*>(t.get())) {
+            type = RT_TEX_IMAGE; a = (int)im->texture_width; b = (int)im->texture_height; off = (int64_t)texels.size();
+            texels.insert(texels.end(), im->texels.begin(), im->texels.end());
+        } else throw std::invalid_argument("unknown texture class");
+        int id = (int)tex_type.size();
+        tex_type.push_back(type); tex_a.push_back(a); tex_b.push_back(b); tex_off.push_back(off);
+        for (int q = 0; q < 3; q++) tex_color.push_back(c[q]);
+        tex_ids[t.get()] = id;
+        return id;
+    }
+    int mat_id(const shared_ptr<material>& m) {
+        auto it = mat_ids.find(m.get());
+        if (it != mat_ids.end()) return it->second;
+        int tex = m->tex ? tex_id(m->tex) : -1;
+        int id = (int)mat_type.size();
+        mat_type.push_back(m->type); mat_tex.push_back(tex);
+        for (int q = 0; q < 3; q++) mat_param.push_back(m->albedo[q]);
+        mat_param.push_back(m->fuzz); mat_param.push_back(m->ir);
+        mat_ids[m.get()] = id;
+        return id;
+    }
+    void add(const shared_ptr<sceneobject>& o) {
+        if (auto l = dynamic_cast<sceneobject_list*>(o.get())) { for (auto& c : l->objects) add(c); return; }
+        double g[6] = {0, 0, 0, 0, 0, 0};
+        if (auto s = dynamic_cast<sphere*>(o.get())) {
+            prim_type.push_back(RT_SPHERE); prim_mat.push_back(mat_id(s->mat_ptr));
+            g[0] = s->center[0]; g[1] = s->center[1]; g[2] = s->center[2]; g[3] = s->radius;
+        } else if (auto r = dynamic_cast<rect_base*>(o.get())) {
+            prim_type.push_back(r->kind); prim_mat.push_back(mat_id(r->mat));
+            g[0] = r->a0; g[1] = r->a1; g[2] = r->b0; g[3] = r->b1; g[4] = r->k;
+        } else throw std::invalid_argument("unknown scene object class");
+        prim_geom.insert(prim_geom.end(), g, g + 6);
+    }
+    explicit flat_scene(const sceneobject_list& world) { for (auto& o : world.objects) add(o); }
+
+    rt_scene_desc desc(int background = RT_BG_SKY, color bg = color(0, 0, 0), int accel = RT_ACCEL_AUTO) const {
+        rt_scene_desc d{};
+        d.struct_size = sizeof(d);
+        d.n_prims = (int32_t)prim_type.size(); d.prim_type = prim_type.data(); d.prim_geom = prim_geom.data(); d.prim_mat = prim_mat.data();
+        d.n_mats = (int32_t)mat_type.size(); d.mat_type = mat_type.data(); d.mat_param = mat_param.data(); d.mat_tex = mat_tex.data();
+        d.n_tex = (int32_t)tex_type.size(); d.tex_type = tex_type.data(); d.tex_color = tex_color.data();
+        d.tex_a = tex_a.data(); d.tex_b = tex_b.data(); d.tex_off = tex_off.data();
+        d.texels = texels.data(); d.texel_bytes = texels.size();
+        d.background = background; d.bg_color[0] = (float)bg[0]; d.bg_color[1] = (float)bg[1]; d.bg_color[2] = (float)bg[2];
+        d.accel = accel; d.wide_radius = 0;
+        return d;
+    }
+};
+
+// ---- renderer ------------------------------------------------------------------------------------
+class renderer {
+public:
+    explicit renderer(int device = 0) { check(rt_create(device, &ctx_), "rt_create"); }
+    ~renderer() { rt_destroy(ctx_); }
+    renderer(const renderer&) = delete;
+    renderer& operator=(const renderer&) = delete;
+
+    void upload(const sceneobject_list& world, int background = RT_BG_SKY, color bg = color(0, 0, 0), int accel = RT_ACCEL_AUTO) {
+        flat_scene f(world);
+        rt_scene_desc d = f.desc(background, bg, accel);
+        check(rt_upload_scene(ctx_, &d), "rt_upload_scene");
+    }
+    void set_camera(const camera& cam) { check(rt_set_camera(ctx_, &cam.d), "rt_set_camera"); }
+
+    // Whole frame into host memory: float4 per pixel, row 0 = bottom row, rgb = radiance sums.
+    std::vector<float> render(int width, int height, int samples_per_pixel, int ray_bounce_limit, uint64_t seed = 1) {
+        rt_render_params p{};
+        p.struct_size = sizeof(p);
+        p.width = width; p.height = height; p.spp = samples_per_pixel; p.max_depth = ray_bounce_limit; p.seed = seed;
+        std::vector<float> out((size_t)width * height * 4);
+        check(rt_render_host(ctx_, &p, out.data()), "rt_render_host");
+        return out;
+    }
+    rt_stats stats() { rt_stats s{}; check(rt_get_stats(ctx_, &s), "rt_get_stats"); return s; }
+    rt_context* context() { return ctx_; }
+
+private:
+    void check(int rc, const char* what) {
+        if (rc != RT_OK) throw std::runtime_error(std::string(what) + ": " + (ctx_ ? rt_last_error(ctx_) : "no gfx950 device"));
+    }
+    rt_context* ctx_ = nullptr;
+};
+
+}  // namespace rt_scene
+#endif
