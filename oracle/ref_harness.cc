@@ -43,7 +43,8 @@ enum { MODE_LIBC = 0, MODE_KEYED = 1, MODE_LIST = 2 };
 struct shim_state {
     int mode = MODE_LIBC;
     uint64_t seed = 0;
-    uint32_t pixel = 0, sample = 0, segment = 0, draw = 0;
+    uint32_t pixel = 0, sample = 0, segment = 0;
+    rto_stream st{};
     const uint32_t* list = nullptr;
     size_t list_n = 0, list_pos = 0;
     uint64_t n_draws = 0;
@@ -56,7 +57,7 @@ struct shim_state {
 struct counting_list : public sceneobject_list {
     bool hit(const ray& r, double t_min, double t_max, hit_record& rec) const override {
         g.segment++;
-        g.draw = 0;
+        rto_stream_begin(&g.st, g.seed, g.pixel, g.sample, g.segment);
         g.n_rays++;
         return sceneobject_list::hit(r, t_min, t_max, rec);
     }
@@ -82,7 +83,7 @@ int rt_ref_rand() {
     g.n_draws++;
     switch (g.mode) {
     case MODE_KEYED: {
-        uint32_t k24 = rto_draw_k24(g.seed, g.pixel, g.sample, g.segment, g.draw++);
+        uint32_t k24 = rto_stream_next(&g.st);
         return (int)(k24 << 7);  // rand()/(RAND_MAX+1.0) == k24 / 2^24
     }
     case MODE_LIST: {
@@ -98,7 +99,8 @@ int rt_ref_rand() {
 void ref_set_mode_libc(void) { g.mode = MODE_LIBC; }
 void ref_set_key(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t segment) {
     g.mode = MODE_KEYED; g.seed = seed; g.pixel = pixel; g.sample = sample;
-    g.segment = segment; g.draw = 0;
+    g.segment = segment;
+    rto_stream_begin(&g.st, seed, pixel, sample, segment);
 }
 void ref_set_draw_list(const uint32_t* k24, size_t n) {
     g.mode = MODE_LIST; g.list = k24; g.list_n = n; g.list_pos = 0;

@@ -83,6 +83,12 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} is missing: build it with `make -C raytrace_amd/csrc` "
                               "(or __graft_entry__.build())")
+        # When PyTorch shares the process it must load its own HIP runtime first: two copies of
+        # libamdhip64 cannot both initialise the GPU, and the first one loaded wins the soname.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         L.rt_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
         L.rt_destroy.argtypes = [C.c_void_p]

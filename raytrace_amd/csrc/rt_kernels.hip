@@ -21,6 +21,7 @@ namespace rt {
 namespace {
 
 constexpr int kBlock = 256;
+constexpr int kSmallStack = 16;
 constexpr float kInf = __builtin_huge_valf();
 
 struct V3 { float x, y, z; };
@@ -53,19 +54,51 @@ __device__ __forceinline__ bool better(float tn, int obj, const Cand& b) {
     return tn < b.tn || (tn == b.tn && obj > b.obj);
 }
 
-// sphere.h:18-41 in double, unnormalised direction, parametric t.
+// 1/x and sqrt(x) in double from the single-precision hardware estimate plus Newton steps
+// (a few fused multiply-adds instead of the library's division and square-root sequences).
+__device__ __forceinline__ double rcp_f64(double x) {
+    double y = (double)(1.0f / (float)x);
+    y = y * fma(-x, y, 2.0);
+    y = y * fma(-x, y, 2.0);
+    return y;
+}
+__device__ __forceinline__ double sqrt_f64(double x) {
+    if (!(x > 1e-30)) return 0.0;
+    double r = (double)rsqrtf((float)x);
+    r = r * fma(-0.5 * x * r, r, 1.5);
+    r = r * fma(-0.5 * x * r, r, 1.5);
+    double s = x * r;
+    return fma(0.5 * r, fma(-s, s, x), s);
+}
+
+// sphere.h:18-41 in double, unnormalised direction, parametric t.  A single-precision look at
+// the same quadratic first drops rays that miss beyond any rounding doubt: origin outside and
+// heading away, or discriminant negative by more than the float error bound.
 __device__ __forceinline__ bool wide_hit(const DWide& w, V3 o, V3 d, double t_min, double t_max, double& t_out) {
+    {
+        float ox = o.x - (float)w.cx, oy = o.y - (float)w.cy, oz = o.z - (float)w.cz;
+        float rr = (float)w.r * (float)w.r;
+        float oo = fmaf(oz, oz, fmaf(oy, oy, ox * ox));
+        float af = fmaf(d.z, d.z, fmaf(d.y, d.y, d.x * d.x));
+        float hbf = fmaf(oz, d.z, fmaf(oy, d.y, ox * d.x));
+        float cf = oo - rr;
+        float scale = oo + rr;
+        bool outside = cf > 1e-4f * scale;
+        if (outside && hbf > 1e-4f * sqrtf(oo * af)) return false;
+        if (outside && fmaf(hbf, hbf, -af * cf) < -1e-4f * af * scale) return false;
+    }
     double ocx = (double)o.x - w.cx, ocy = (double)o.y - w.cy, ocz = (double)o.z - w.cz;
     double dx = d.x, dy = d.y, dz = d.z;
-    double a = dx * dx + dy * dy + dz * dz;
-    double b = 2.0 * (ocx * dx + ocy * dy + ocz * dz);
-    double c = (ocx * ocx + ocy * ocy + ocz * ocz) - w.r * w.r;
-    double disc = b * b - 4.0 * a * c;
+    double a = fma(dz, dz, fma(dy, dy, dx * dx));
+    double hb = fma(ocz, dz, fma(ocy, dy, ocx * dx));
+    double c = fma(ocz, ocz, fma(ocy, ocy, ocx * ocx)) - w.r * w.r;
+    double disc = fma(hb, hb, -a * c);          // (b*b - 4ac) / 4
     if (disc < 0.0) return false;
-    double sq = sqrt(disc);
-    double root = (-b - sq) / (2.0 * a);
+    double sq = sqrt_f64(disc);
+    double inv_a = rcp_f64(a);
+    double root = (-hb - sq) * inv_a;
     if (root < t_min || root > t_max) {
-        root = (-b + sq) / (2.0 * a);
+        root = (-hb + sq) * inv_a;
         if (root < t_min || root > t_max) return false;
     }
     t_out = root;
@@ -354,14 +387,33 @@ struct Key { uint32_t seed_lo, seed_hi, pixel, sample; };
 __device__ __forceinline__ float u01(uint32_t w) { return (float)(w >> 8) * 5.9604644775390625e-08f; }  // 2^-24
 __device__ __forceinline__ float pm1(uint32_t w) { return fmaf(2.0f, u01(w), -1.0f); }                   // random_double(-1,1)
 
-// vec3.h:130-136.  Attempt i of a scatter segment reads words 0,1,2 of block i: the first draw
-// is z, then y, then x (argument evaluation order of the reference build, vec3.h:60).
+// xoshiro128++ (Blackman, Vigna): the draws of a segment beyond its Philox block.
+struct Xo { uint32_t s0, s1, s2, s3; };
+__device__ __forceinline__ uint32_t rotl32(uint32_t x, int k) { return __builtin_rotateleft32(x, k); }
+__device__ __forceinline__ uint32_t xo_next(Xo& g) {
+    uint32_t result = rotl32(g.s0 + g.s3, 7) + g.s0;
+    uint32_t t = g.s1 << 9;
+    g.s2 ^= g.s0; g.s3 ^= g.s1; g.s1 ^= g.s2; g.s0 ^= g.s3;
+    g.s2 ^= t;
+    g.s3 = rotl32(g.s3, 11);
+    return result;
+}
+
+// vec3.h:130-136.  The first rejection attempt of a scatter segment reads words 0,1,2 of the
+// segment's Philox block (first draw z, then y, then x: the argument evaluation order of the
+// reference build, vec3.h:60); later attempts step xoshiro128++ from the block.
 __device__ __forceinline__ V3 in_unit_sphere(const Key& k, uint32_t segment) {
-    for (uint32_t i = 0;; i++) {
-        uint4 w = philox4x32_10(k.pixel, k.sample, segment, i, k.seed_lo, k.seed_hi);
-        V3 p = mk(pm1(w.z), pm1(w.y), pm1(w.x));
-        if (!(dot(p, p) >= 1.0f) || i > 64) return p;
+    uint4 w = philox4x32_10(k.pixel, k.sample, segment, 0u, k.seed_lo, k.seed_hi);
+    V3 p = mk(pm1(w.z), pm1(w.y), pm1(w.x));
+    if (dot(p, p) >= 1.0f) {
+        Xo g; g.s0 = w.x; g.s1 = w.y; g.s2 = w.z; g.s3 = w.w;
+        for (int i = 0; i < 256; i++) {
+            float z = pm1(xo_next(g)), y = pm1(xo_next(g)), x = pm1(xo_next(g));
+            p = mk(x, y, z);
+            if (!(dot(p, p) >= 1.0f)) break;
+        }
     }
+    return p;
 }
 
 // ---- materials (material.h:15-92; emitters cuda/material.h:33-47,103-119) -------------------------------------
@@ -424,9 +476,9 @@ __device__ __forceinline__ bool scatter(const DScene& sc, const DMaterial& m, V3
 
 // ---- camera (camera.h:40-45, main.cc:117-118) ---------------------------------------------------------------------
 
-// Segment 0 of a sample: draws 0,1 jitter the pixel (block 0 words 0,1); disk attempt 0 reads
-// block 0 words 2,3 (first draw y, second x, vec3.h:152), attempt a >= 1 reads words
-// 2*((a+1)&1) and +1 of block (a+1)>>1.
+// Segment 0 of a sample: its Philox block holds the two pixel jitters (words 0,1) and the first
+// lens-disk attempt (word 2 -> y, word 3 -> x: vec3.h:152 evaluated right to left); further
+// attempts step xoshiro128++ from the block.
 __device__ __forceinline__ void camera_ray(const DCamera& cam, const DRender& rp, const Key& k, int i, int j, V3& o, V3& d) {
     uint4 w = philox4x32_10(k.pixel, k.sample, 0u, 0u, k.seed_lo, k.seed_hi);
     float s = ((float)i + u01(w.x)) * rp.inv_wm1;
@@ -434,12 +486,11 @@ __device__ __forceinline__ void camera_ray(const DCamera& cam, const DRender& rp
     V3 offset = mk(0.0f, 0.0f, 0.0f);
     if (cam.lens_radius != 0.0f) {
         float py = pm1(w.z), px = pm1(w.w);
-        for (uint32_t a = 1; fmaf(px, px, py * py) >= 1.0f && a < 64; a++) {
-            if ((a & 1u) != 0u) {
-                w = philox4x32_10(k.pixel, k.sample, 0u, (a + 1u) >> 1, k.seed_lo, k.seed_hi);
-                py = pm1(w.x); px = pm1(w.y);
-            } else {
-                py = pm1(w.z); px = pm1(w.w);
+        if (fmaf(px, px, py * py) >= 1.0f) {
+            Xo g; g.s0 = w.x; g.s1 = w.y; g.s2 = w.z; g.s3 = w.w;
+            for (int a = 0; a < 256; a++) {
+                py = pm1(xo_next(g)); px = pm1(xo_next(g));
+                if (!(fmaf(px, px, py * py) >= 1.0f)) break;
             }
         }
         float rx = cam.lens_radius * px, ry = cam.lens_radius * py;
@@ -467,10 +518,10 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
 
 // ---- render kernel ---------------------------------------------------------------------------------------------------
 
-template <bool COUNT>
+template <bool COUNT, int STACK>
 __global__ __launch_bounds__(kBlock) void render_kernel(DScene sc, DCamera cam, DRender rp, float4* __restrict__ out,
                                                         unsigned long long* __restrict__ counters) {
-    __shared__ int s_stack[kMaxStack * kBlock];
+    __shared__ int s_stack[STACK * kBlock];
     int* stack = s_stack + threadIdx.x;
 
     const int lane = threadIdx.x & 63;
@@ -629,10 +680,14 @@ hipError_t launch_render(const DScene& sc, const DCamera& cam, const DRender& rp
     const long long blocks = (tiles + (kBlock / 64) - 1) / (kBlock / 64);
     if (blocks <= 0) return hipSuccess;
     if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-    if (rp.flags & 4u)
-        hipLaunchKernelGGL(render_kernel<true>, dim3((unsigned)blocks), dim3(kBlock), 0, stream, sc, cam, rp, out, counters);
-    else
-        hipLaunchKernelGGL(render_kernel<false>, dim3((unsigned)blocks), dim3(kBlock), 0, stream, sc, cam, rp, out, counters);
+    // the traversal stack holds one entry per BVH level: shallow trees get the small LDS footprint
+    const bool small = sc.bvh_depth + 2 <= kSmallStack;
+    const bool count = (rp.flags & 4u) != 0u;
+    dim3 grid((unsigned)blocks), block(kBlock);
+    if (count && small) hipLaunchKernelGGL((render_kernel<true, kSmallStack>), grid, block, 0, stream, sc, cam, rp, out, counters);
+    else if (count) hipLaunchKernelGGL((render_kernel<true, kMaxStack>), grid, block, 0, stream, sc, cam, rp, out, counters);
+    else if (small) hipLaunchKernelGGL((render_kernel<false, kSmallStack>), grid, block, 0, stream, sc, cam, rp, out, counters);
+    else hipLaunchKernelGGL((render_kernel<false, kMaxStack>), grid, block, 0, stream, sc, cam, rp, out, counters);
     return hipGetLastError();
 }
 

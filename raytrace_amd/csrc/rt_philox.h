@@ -1,9 +1,11 @@
 // Philox4x32-10 (Salmon et al., SC'11), the counter-based generator behind every random draw of
 // the render path.  It replaces the reference's global rand() (utils.h:25) and the per-pixel
 // curandState of cuda/main.cu:281-291,340-348: a draw is a pure function of
-//     counter = (pixel, sample, segment, block)   key = (seed_lo, seed_hi)
+//     counter = (pixel, sample, segment, 0)   key = (seed_lo, seed_hi)
 // where segment 0 holds a sample's camera draws and segment k >= 1 the scatter draws after the
-// k-th closest-hit query.  Uniforms are (word >> 8) * 2^-24, in [0,1) like random_double().
+// k-th closest-hit query.  The block's words are the segment's first draws; a rejection loop
+// that needs more steps xoshiro128++ from the block (rt_kernels.hip).  Uniforms are
+// (word >> 8) * 2^-24, in [0,1) like random_double().
 #pragma once
 
 #include <hip/hip_runtime.h>
