@@ -94,7 +94,8 @@ typedef struct rt_camera_desc {
 enum {
     RT_FLAG_MEAN = 1u << 0,       /* rgb = mean radiance instead of the sum over samples */
     RT_FLAG_NO_REFINE = 1u << 1,  /* skip the double-precision polish of the winning hit */
-    RT_FLAG_COUNTERS = 1u << 2    /* also count box/sphere/rect tests (slower; for the roofline) */
+    RT_FLAG_COUNTERS = 1u << 2,   /* also count box/sphere/rect tests (slower; for the roofline) */
+    RT_FLAG_PHASE_CLOCKS = 1u << 3 /* diagnostic build: wave clocks per phase into rt_stats.phase_clocks */
 };
 
 typedef struct rt_render_params {
@@ -126,6 +127,7 @@ typedef struct rt_stats {
     uint64_t rays;               /* closest-hit queries (one per world.hit call, main.cc:18) */
     uint64_t samples;            /* camera samples */
     uint64_t box_tests, sphere_tests, sphere_hits, rect_tests, wide_tests, shades; /* RT_FLAG_COUNTERS */
+    uint64_t phase_clocks[5];    /* RT_FLAG_PHASE_CLOCKS: camera, always-tested, traversal, record, scatter */
     float kernel_ms;             /* device time of the last render kernel (HIP events on its stream) */
     int32_t lanes_per_pixel;     /* value the last render used */
     int32_t accel;               /* RT_ACCEL_LIST or RT_ACCEL_BVH actually used */

@@ -14,7 +14,7 @@ RT_OK = 0
 RT_ERR_INVALID, RT_ERR_NO_DEVICE, RT_ERR_HIP, RT_ERR_NO_SCENE, RT_ERR_NO_CAMERA, RT_ERR_UNSUPPORTED = \
     -1, -2, -3, -4, -5, -6
 RT_ACCEL_AUTO, RT_ACCEL_LIST, RT_ACCEL_BVH = 0, 1, 2
-RT_FLAG_MEAN, RT_FLAG_NO_REFINE, RT_FLAG_COUNTERS = 1, 2, 4
+RT_FLAG_MEAN, RT_FLAG_NO_REFINE, RT_FLAG_COUNTERS, RT_FLAG_PHASE_CLOCKS = 1, 2, 4, 8
 
 EXPORTS = ["rt_create", "rt_destroy", "rt_set_stream", "rt_upload_scene", "rt_set_camera",
            "rt_shard_rows", "rt_render", "rt_render_host", "rt_trace_primary", "rt_quantize",
@@ -65,12 +65,15 @@ HIT_DTYPE = np.dtype([("id", "<i4"), ("t", "<f4"), ("p", "<f4", 3), ("n", "<f4",
 class Stats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("samples", C.c_uint64), ("box_tests", C.c_uint64),
                 ("sphere_tests", C.c_uint64), ("sphere_hits", C.c_uint64), ("rect_tests", C.c_uint64),
-                ("wide_tests", C.c_uint64), ("shades", C.c_uint64), ("kernel_ms", C.c_float),
+                ("wide_tests", C.c_uint64), ("shades", C.c_uint64), ("phase_clocks", C.c_uint64 * 5),
+                ("kernel_ms", C.c_float),
                 ("lanes_per_pixel", C.c_int32), ("accel", C.c_int32), ("bvh_nodes", C.c_int32),
                 ("bvh_depth", C.c_int32)]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_}
+        d = {k: getattr(self, k) for k, _ in self._fields_}
+        d["phase_clocks"] = [int(x) for x in self.phase_clocks]
+        return d
 
 
 _lib = None

@@ -160,7 +160,7 @@ int validate_render(rt_context* ctx, const rt_render_params* p, rt::DRender* rp)
 }
 
 int do_render(rt_context* ctx, const rt::DRender& rp, float4* out_dev) {
-    RT_HIP(ctx, hipMemsetAsync(ctx->counters, 0, rt::kNumCounters * sizeof(unsigned long long), ctx->stream));
+    RT_HIP(ctx, hipMemsetAsync(ctx->counters, 0, (rt::kNumCounters + rt::kNumPhaseClocks) * sizeof(unsigned long long), ctx->stream));
     RT_HIP(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
     RT_HIP(ctx, rt::launch_render(ctx->scene, ctx->camera, rp, out_dev, ctx->counters, ctx->stream));
     RT_HIP(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
@@ -187,7 +187,7 @@ int rt_create(int device, rt_context** out) {
     if (!ctx) return RT_ERR_INVALID;
     ctx->device = device;
     DeviceGuard g(device);
-    if (hipMalloc((void**)&ctx->counters, rt::kNumCounters * sizeof(unsigned long long)) != hipSuccess ||
+    if (hipMalloc((void**)&ctx->counters, (rt::kNumCounters + rt::kNumPhaseClocks) * sizeof(unsigned long long)) != hipSuccess ||
         hipEventCreate(&ctx->ev_start) != hipSuccess || hipEventCreate(&ctx->ev_stop) != hipSuccess) {
         rt_destroy(ctx);
         return RT_ERR_HIP;
@@ -460,11 +460,12 @@ int rt_get_stats(rt_context* ctx, rt_stats* out) {
     DeviceGuard g(ctx->device);
     std::memset(out, 0, sizeof(*out));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    unsigned long long c[rt::kNumCounters];
+    unsigned long long c[rt::kNumCounters + rt::kNumPhaseClocks];
     RT_HIP(ctx, hipMemcpy(c, ctx->counters, sizeof(c), hipMemcpyDeviceToHost));
     out->rays = c[0]; out->samples = c[1];
     out->box_tests = c[2]; out->sphere_tests = c[3]; out->sphere_hits = c[4];
     out->rect_tests = c[5]; out->wide_tests = c[6]; out->shades = c[7];
+    for (int q = 0; q < rt::kNumPhaseClocks; q++) out->phase_clocks[q] = c[rt::kNumCounters + q];
     if (ctx->timed) RT_HIP(ctx, hipEventElapsedTime(&out->kernel_ms, ctx->ev_start, ctx->ev_stop));
     out->lanes_per_pixel = ctx->last_k;
     out->accel = ctx->accel_used;

@@ -87,6 +87,7 @@ struct DRender {
 // counters[0] rays, [1] samples, [2] box tests, [3] sphere tests, [4] sphere hits,
 // [5] rect tests, [6] wide tests, [7] shades
 constexpr int kNumCounters = 8;
+constexpr int kNumPhaseClocks = 5;         // extra slots behind the counters (diagnostic build)
 constexpr int kNoBvh = 0x7fffffff;
 constexpr int kMaxStack = 48;               // deepest BVH the traversal stack holds
 

@@ -166,19 +166,32 @@ __device__ __forceinline__ void leaf_spheres(const DScene& sc, int first, int co
     }
 }
 
-// Closest hit over the whole scene.  `stack` is this lane's column of the workgroup's LDS
-// traversal stack (entry e at stack[e * kBlock]).
-template <bool COUNT>
-__device__ __forceinline__ Cand closest_hit(const DScene& sc, V3 o, V3 d, float t_min, int* stack, Counters& cn) {
+__device__ __forceinline__ Cand no_hit() {
     Cand best;
     best.tn = kInf; best.td = 0.0; best.kind = -1; best.idx = -1; best.obj = -1;
-    float len2 = dot(d, d);
-    float len = sqrtf(len2);
-    float inv_len = 1.0f / len;
-    V3 dh = inv_len * d;
-    float tn_min = t_min * len;
+    return best;
+}
 
-    // always-tested primitives: wide spheres (double) and rects
+// Per-ray constants of the closest-hit query.
+struct RayN {
+    V3 dh;          // unit direction
+    float len;      // |d|
+    float inv_len;
+    float tn_min;   // t_min along the unit direction
+};
+__device__ __forceinline__ RayN normalise(V3 d, float t_min) {
+    RayN r;
+    r.len = sqrtf(dot(d, d));
+    r.inv_len = 1.0f / r.len;
+    r.dh = r.inv_len * d;
+    r.tn_min = t_min * r.len;
+    return r;
+}
+
+// Always-tested primitives: wide spheres (double) and rects.  They run first and tighten the
+// distance bound the BVH traversal prunes with.
+template <bool COUNT>
+__device__ __forceinline__ void hit_always(const DScene& sc, V3 o, V3 d, const RayN& rn, float t_min, Cand& best, Counters& cn) {
     for (int i = 0; i < sc.n_wide; i++) {
         const DWide w = sc.wide[i];
         double t;
@@ -186,7 +199,7 @@ __device__ __forceinline__ Cand closest_hit(const DScene& sc, V3 o, V3 d, float 
         // only wide spheres have been seen so far: compare in double, later object wins a tie
         double tmax = best.kind < 0 ? (double)kInf : best.td;
         if (wide_hit(w, o, d, (double)t_min, tmax, t) && (best.kind < 0 || t < best.td || w.obj > best.obj)) {
-            best.tn = (float)(t * (double)len); best.td = t; best.kind = 1; best.idx = i; best.obj = w.obj;
+            best.tn = (float)(t * (double)rn.len); best.td = t; best.kind = 1; best.idx = i; best.obj = w.obj;
         }
     }
     for (int i = 0; i < sc.n_rects; i++) {
@@ -194,27 +207,25 @@ __device__ __forceinline__ Cand closest_hit(const DScene& sc, V3 o, V3 d, float 
         float t;
         if (COUNT) cn.rect++;
         if (rect_test(r, o, d, t_min, kInf, t)) {
-            float tn = t * len;
+            float tn = t * rn.len;
             if (better(tn, r.obj, best)) { best.tn = tn; best.td = (double)t; best.kind = 2; best.idx = i; best.obj = r.obj; }
         }
     }
+}
 
-    if (!sc.use_bvh) {
-        // sceneobject_list.h:26-39: every ordinary sphere, in list order
-        for (int i = 0; i < sc.n_sph; i++) {
-            float4 s = sc.sph[i];
-            float tn;
-            if (COUNT) cn.sph++;
-            if (sphere_test(s, o, dh, tn_min, best.tn, tn)) {
-                int obj = sc.sph_info[i].x;
-                if (COUNT) cn.sph_hit++;
-                if (better(tn, obj, best)) { best.tn = tn; best.kind = 0; best.idx = i; best.obj = obj; }
-            }
-        }
-        return best;
-    }
+// sceneobject_list.h:26-39: every ordinary sphere, in list order.
+template <bool COUNT>
+__device__ __forceinline__ void hit_list(const DScene& sc, V3 o, const RayN& rn, Cand& best, Counters& cn) {
+    leaf_spheres<COUNT>(sc, 0, sc.n_sph, o, rn.dh, rn.tn_min, best, cn);
+}
 
-    if (sc.root == kNoBvh) return best;
+// BVH traversal, near child first.  `stack` is this lane's column of the workgroup's LDS
+// traversal stack (entry e at stack[e * kBlock]).
+template <bool COUNT>
+__device__ __forceinline__ void hit_bvh(const DScene& sc, V3 o, const RayN& rn, int* stack, Cand& best, Counters& cn) {
+    if (sc.root == kNoBvh) return;
+    const V3 dh = rn.dh;
+    const float tn_min = rn.tn_min;
     V3 idir = mk(1.0f / dh.x, 1.0f / dh.y, 1.0f / dh.z);
     int sp = 0;
     int cur = sc.root;
@@ -246,6 +257,16 @@ __device__ __forceinline__ Cand closest_hit(const DScene& sc, V3 o, V3 d, float 
         sp--;
         cur = stack[sp * kBlock];
     }
+}
+
+// Closest hit over the whole scene.
+template <bool COUNT>
+__device__ __forceinline__ Cand closest_hit(const DScene& sc, V3 o, V3 d, float t_min, int* stack, Counters& cn) {
+    Cand best = no_hit();
+    RayN rn = normalise(d, t_min);
+    hit_always<COUNT>(sc, o, d, rn, t_min, best, cn);
+    if (sc.use_bvh) hit_bvh<COUNT>(sc, o, rn, stack, best, cn);
+    else hit_list<COUNT>(sc, o, rn, best, cn);
     return best;
 }
 
@@ -258,10 +279,12 @@ struct Rec {
     int front, mat, obj;
 };
 
-// cuda/sphere.h:20-26 on the unit outward normal
+// cuda/sphere.h:20-26 on the unit outward normal.  theta = acos(-y) is taken as
+// atan2(|(x,z)|, -y): the same angle, but well conditioned at the poles where acos turns a
+// 1e-7 error of y into 4e-4 of theta.
 __device__ __forceinline__ void sphere_uv(V3 on, float& u, float& v) {
     const float pi = 3.14159265358979323846f;
-    float theta = acosf(fminf(fmaxf(-on.y, -1.0f), 1.0f));
+    float theta = atan2f(sqrtf(fmaf(on.x, on.x, on.z * on.z)), -on.y);
     float phi = atan2f(-on.z, on.x) + pi;
     u = phi * (1.0f / (2.0f * pi));
     v = theta * (1.0f / pi);
@@ -518,7 +541,9 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
 
 // ---- render kernel ---------------------------------------------------------------------------------------------------
 
-template <bool COUNT, int STACK>
+__device__ __forceinline__ unsigned long long clk() { return __builtin_amdgcn_s_memtime(); }
+
+template <bool COUNT, int STACK, bool PROF>
 __global__ __launch_bounds__(kBlock) void render_kernel(DScene sc, DCamera cam, DRender rp, float4* __restrict__ out,
                                                         unsigned long long* __restrict__ counters) {
     __shared__ int s_stack[STACK * kBlock];
@@ -557,7 +582,9 @@ __global__ __launch_bounds__(kBlock) void render_kernel(DScene sc, DCamera cam, 
     bool fresh = true;
     V3 o = mk(0, 0, 0), d = mk(0, 0, 1), T = mk(1, 1, 1);
     int depth = 0;
+    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, tq = 0;
     while (alive) {
+        if (PROF) tq = clk();
         if (fresh) {
             key.sample = (uint32_t)s;
             camera_ray(cam, rp, key, x, j, o, d);
@@ -566,7 +593,14 @@ __global__ __launch_bounds__(kBlock) void render_kernel(DScene sc, DCamera cam, 
             fresh = false;
             nsamples++;
         }
-        Cand c = closest_hit<COUNT>(sc, o, d, rp.t_min, stack, cn);
+        if (PROF) { unsigned long long t = clk(); ph[0] += t - tq; tq = t; }
+        Cand c = no_hit();
+        RayN rn = normalise(d, rp.t_min);
+        hit_always<COUNT>(sc, o, d, rn, rp.t_min, c, cn);
+        if (PROF) { unsigned long long t = clk(); ph[1] += t - tq; tq = t; }
+        if (sc.use_bvh) hit_bvh<COUNT>(sc, o, rn, stack, c, cn);
+        else hit_list<COUNT>(sc, o, rn, c, cn);
+        if (PROF) { unsigned long long t = clk(); ph[2] += t - tq; tq = t; }
         nrays++;
         depth++;
         bool done;
@@ -577,6 +611,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel(DScene sc, DCamera cam, 
             int mat = c.kind == 0 ? sc.sph_info[c.idx].y : (c.kind == 1 ? sc.wide[c.idx].mat : sc.rects[c.idx].mat);
             const DMaterial m = sc.mats[mat];
             Rec r = make_record(sc, c, o, d, refine, m.tex >= 0);
+            if (PROF) { unsigned long long t = clk(); ph[3] += t - tq; tq = t; }
             V3 att, sd, em;
             if (COUNT) cn.shade++;
             bool cont = scatter(sc, m, d, r, key, (uint32_t)depth, att, sd, em);
@@ -591,6 +626,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel(DScene sc, DCamera cam, 
             fresh = true;
             alive = s < s_end;
         }
+        if (PROF) { unsigned long long t = clk(); ph[4] += t - tq; tq = t; }
     }
 
     // combine the K slices of each pixel in lane order, then one float4 store per pixel
@@ -614,6 +650,10 @@ __global__ __launch_bounds__(kBlock) void render_kernel(DScene sc, DCamera cam, 
     if (lane == 0 && r_all) {
         atomicAdd(&counters[0], r_all);
         atomicAdd(&counters[1], s_all);
+    }
+    if (PROF && lane == 0) {
+        // wave-level clocks per phase: camera, always-tested primitives, traversal, record, scatter
+        for (int q = 0; q < 5; q++) atomicAdd(&counters[kNumCounters + q], ph[q]);
     }
     if (COUNT) {
         unsigned long long v[6] = {cn.box, cn.sph, cn.sph_hit, cn.rect, cn.wide, cn.shade};
@@ -684,10 +724,13 @@ hipError_t launch_render(const DScene& sc, const DCamera& cam, const DRender& rp
     const bool small = sc.bvh_depth + 2 <= kSmallStack;
     const bool count = (rp.flags & 4u) != 0u;
     dim3 grid((unsigned)blocks), block(kBlock);
-    if (count && small) hipLaunchKernelGGL((render_kernel<true, kSmallStack>), grid, block, 0, stream, sc, cam, rp, out, counters);
-    else if (count) hipLaunchKernelGGL((render_kernel<true, kMaxStack>), grid, block, 0, stream, sc, cam, rp, out, counters);
-    else if (small) hipLaunchKernelGGL((render_kernel<false, kSmallStack>), grid, block, 0, stream, sc, cam, rp, out, counters);
-    else hipLaunchKernelGGL((render_kernel<false, kMaxStack>), grid, block, 0, stream, sc, cam, rp, out, counters);
+    const bool prof = (rp.flags & 8u) != 0u;
+    if (prof && small) hipLaunchKernelGGL((render_kernel<false, kSmallStack, true>), grid, block, 0, stream, sc, cam, rp, out, counters);
+    else if (prof) hipLaunchKernelGGL((render_kernel<false, kMaxStack, true>), grid, block, 0, stream, sc, cam, rp, out, counters);
+    else if (count && small) hipLaunchKernelGGL((render_kernel<true, kSmallStack, false>), grid, block, 0, stream, sc, cam, rp, out, counters);
+    else if (count) hipLaunchKernelGGL((render_kernel<true, kMaxStack, false>), grid, block, 0, stream, sc, cam, rp, out, counters);
+    else if (small) hipLaunchKernelGGL((render_kernel<false, kSmallStack, false>), grid, block, 0, stream, sc, cam, rp, out, counters);
+    else hipLaunchKernelGGL((render_kernel<false, kMaxStack, false>), grid, block, 0, stream, sc, cam, rp, out, counters);
     return hipGetLastError();
 }
 

@@ -27,3 +27,6 @@ for k in (2, 4, 8):
 cst = run("counters", reps=1, flags=api.RT_FLAG_COUNTERS)
 r = cst["rays"]
 print({k: round(v / r, 3) for k, v in cst.items() if k.endswith("tests") or k in ("sphere_hits", "shades", "samples")})
+pst = run("phase clocks", reps=1, flags=api.RT_FLAG_PHASE_CLOCKS)
+pc = np.array(pst["phase_clocks"], dtype=np.float64)
+print("phase share: camera %.3f always %.3f traversal %.3f record %.3f scatter %.3f" % tuple(pc / pc.sum()))
