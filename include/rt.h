@@ -95,7 +95,8 @@ enum {
     RT_FLAG_MEAN = 1u << 0,       /* rgb = mean radiance instead of the sum over samples */
     RT_FLAG_NO_REFINE = 1u << 1,  /* skip the double-precision polish of the winning hit */
     RT_FLAG_COUNTERS = 1u << 2,   /* also count box/sphere/rect tests (slower; for the roofline) */
-    RT_FLAG_PHASE_CLOCKS = 1u << 3 /* diagnostic build: wave clocks per phase into rt_stats.phase_clocks */
+    RT_FLAG_PHASE_CLOCKS = 1u << 3, /* diagnostic build: wave clocks per phase into rt_stats.phase_clocks */
+    RT_FLAG_NO_LDS_SCENE = 1u << 5 /* read BVH and spheres from HBM even when they would fit in LDS */
 };
 
 typedef struct rt_render_params {
@@ -110,7 +111,8 @@ typedef struct rt_render_params {
     int32_t tile_step;           /* and packs their rows in that order.  0,0,0 = whole image */
     float t_min;                 /* main.cc:18 uses 0.001; 0 selects that */
     uint32_t flags;              /* RT_FLAG_* */
-    int32_t lanes_per_pixel;     /* 1,2,4,...,64 lanes share a pixel's samples; 0 = choose */
+    int32_t lanes_per_pixel;     /* K = 1,2,4,...,64: a wavefront's tile holds 64/K pixels whose samples its
+                                    64 lanes take dynamically; 0 = choose from the frame size */
 } rt_render_params;
 
 /* one closest-hit answer (hit_record of sceneobject.h:9-14 plus the object's list position) */

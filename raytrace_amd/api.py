@@ -14,7 +14,7 @@ RT_OK = 0
 RT_ERR_INVALID, RT_ERR_NO_DEVICE, RT_ERR_HIP, RT_ERR_NO_SCENE, RT_ERR_NO_CAMERA, RT_ERR_UNSUPPORTED = \
     -1, -2, -3, -4, -5, -6
 RT_ACCEL_AUTO, RT_ACCEL_LIST, RT_ACCEL_BVH = 0, 1, 2
-RT_FLAG_MEAN, RT_FLAG_NO_REFINE, RT_FLAG_COUNTERS, RT_FLAG_PHASE_CLOCKS = 1, 2, 4, 8
+RT_FLAG_MEAN, RT_FLAG_NO_REFINE, RT_FLAG_COUNTERS, RT_FLAG_PHASE_CLOCKS, RT_FLAG_NO_LDS_SCENE = 1, 2, 4, 8, 32
 
 EXPORTS = ["rt_create", "rt_destroy", "rt_set_stream", "rt_upload_scene", "rt_set_camera",
            "rt_shard_rows", "rt_render", "rt_render_host", "rt_trace_primary", "rt_quantize",

@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -365,6 +366,7 @@ int rt_upload_scene(rt_context* ctx, const rt_scene_desc* d) {
         return rc;
     }
     s.n_sph = (int)ns;
+    s.n_nodes = (int)(bvh.nodes.size() / 16);
     s.root = use_bvh ? bvh.root : rt::kNoBvh;
     s.bvh_depth = bvh.depth;
     s.use_bvh = use_bvh ? 1 : 0;

@@ -49,6 +49,7 @@ struct DScene {
     const int2* sph_info;
     int n_sph;
     const float4* nodes;
+    int n_nodes;
     int root;             // inner index, leaf code, or kNoBvh
     int bvh_depth;
     int use_bvh;          // 0: scan all ordinary spheres in order
@@ -80,8 +81,9 @@ struct DRender {
     int rows;                               // rows this launch renders
     float t_min;
     uint32_t flags;
-    int lanes_per_pixel;                    // K: power of two, 1..64
+    int lanes_per_pixel;                    // K: power of two, 1..64; a wave's tile holds 64/K pixels
     float inv_wm1, inv_hm1;                 // 1/(W-1), 1/(H-1)  (main.cc:117-118)
+    int stack_depth;                        // entries per lane of the LDS traversal stack
 };
 
 // counters[0] rays, [1] samples, [2] box tests, [3] sphere tests, [4] sphere hits,

@@ -21,7 +21,6 @@ namespace rt {
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kSmallStack = 16;
 constexpr float kInf = __builtin_huge_valf();
 
 struct V3 { float x, y, z; };
@@ -37,7 +36,13 @@ __device__ __forceinline__ float dot(V3 a, V3 b) { return fmaf(a.z, b.z, fmaf(a.
 __device__ __forceinline__ V3 madd(V3 a, float s, V3 b) { return mk(fmaf(s, b.x, a.x), fmaf(s, b.y, a.y), fmaf(s, b.z, a.z)); }
 __device__ __forceinline__ float comp(V3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
 
-struct Counters { unsigned box, sph, sph_hit, rect, wide, shade; };
+struct Counters { unsigned box, sph, sph_hit, rect, wide, shade, steps, wave_steps; };
+
+// true in exactly one of the currently active lanes
+__device__ __forceinline__ bool first_active_lane() {
+    int lane = (int)(threadIdx.x & 63);
+    return __builtin_amdgcn_readfirstlane(lane) == lane;
+}
 
 // ---- closest hit ---------------------------------------------------------------------------
 
@@ -151,15 +156,30 @@ __device__ __forceinline__ bool box_test(float bx0, float by0, float bz0, float 
     return tnear <= tfar * 1.0000005f;
 }
 
-template <bool COUNT>
-__device__ __forceinline__ void leaf_spheres(const DScene& sc, int first, int count, V3 o, V3 dh,
+// Where the traversal reads its geometry from: HBM (through L1/L2), or a copy in LDS that the
+// workgroup makes at kernel start when the whole BVH and sphere list fit.
+struct GeoGlobal {
+    const float4* nodes; const float4* sph; const int2* info;
+    __device__ __forceinline__ float4 node(int i, int q) const { return nodes[4 * (size_t)i + q]; }
+    __device__ __forceinline__ float4 sphere(int i) const { return sph[i]; }
+    __device__ __forceinline__ int obj(int i) const { return info[i].x; }
+};
+struct GeoLds {
+    const float4* nodes; const float4* sph; const int* objs;     // all three point into LDS
+    __device__ __forceinline__ float4 node(int i, int q) const { return nodes[4 * i + q]; }
+    __device__ __forceinline__ float4 sphere(int i) const { return sph[i]; }
+    __device__ __forceinline__ int obj(int i) const { return objs[i]; }
+};
+
+template <bool COUNT, class G>
+__device__ __forceinline__ void leaf_spheres(const G& geo, int first, int count, V3 o, V3 dh,
                                              float tn_min, Cand& best, Counters& cn) {
     for (int i = first; i < first + count; i++) {
-        float4 s = sc.sph[i];
+        float4 s = geo.sphere(i);
         float tn;
         if (COUNT) cn.sph++;
         if (sphere_test(s, o, dh, tn_min, best.tn, tn)) {
-            int obj = sc.sph_info[i].x;
+            int obj = geo.obj(i);
             if (COUNT) cn.sph_hit++;
             if (better(tn, obj, best)) { best.tn = tn; best.kind = 0; best.idx = i; best.obj = obj; }
         }
@@ -214,25 +234,31 @@ __device__ __forceinline__ void hit_always(const DScene& sc, V3 o, V3 d, const R
 }
 
 // sceneobject_list.h:26-39: every ordinary sphere, in list order.
-template <bool COUNT>
-__device__ __forceinline__ void hit_list(const DScene& sc, V3 o, const RayN& rn, Cand& best, Counters& cn) {
-    leaf_spheres<COUNT>(sc, 0, sc.n_sph, o, rn.dh, rn.tn_min, best, cn);
+template <bool COUNT, class G>
+__device__ __forceinline__ void hit_list(const DScene& sc, const G& geo, V3 o, const RayN& rn, Cand& best, Counters& cn) {
+    leaf_spheres<COUNT>(geo, 0, sc.n_sph, o, rn.dh, rn.tn_min, best, cn);
 }
 
-// BVH traversal, near child first.  `stack` is this lane's column of the workgroup's LDS
-// traversal stack (entry e at stack[e * kBlock]).
-template <bool COUNT>
-__device__ __forceinline__ void hit_bvh(const DScene& sc, V3 o, const RayN& rn, int* stack, Cand& best, Counters& cn) {
+// BVH traversal, near child first, as two nested loops: the inner one walks inner nodes until
+// every lane of the wave stands on a leaf (or has finished), then all those lanes test their
+// leaves together.  A leaf costs as much as two node steps and only one lane step in eight is
+// a leaf, so testing leaves as they come would run the sphere code for a handful of lanes on
+// nearly every trip.  `stack` is this lane's column of the workgroup's LDS traversal stack
+// (entry e at stack[e * kBlock]).
+constexpr int kTravDone = (int)0x80000000;     // not a leaf code: ~kTravDone >> 2 exceeds any sphere count
+
+template <bool COUNT, class G>
+__device__ __forceinline__ void hit_bvh(const DScene& sc, const G& geo, V3 o, const RayN& rn, int* stack, Cand& best, Counters& cn) {
     if (sc.root == kNoBvh) return;
     const V3 dh = rn.dh;
     const float tn_min = rn.tn_min;
     V3 idir = mk(1.0f / dh.x, 1.0f / dh.y, 1.0f / dh.z);
     int sp = 0;
     int cur = sc.root;
-    for (;;) {
-        if (cur >= 0) {
-            const float4* n = sc.nodes + 4 * (size_t)cur;
-            float4 q0 = n[0], q1 = n[1], q2 = n[2], q3 = n[3];
+    while (cur != kTravDone) {
+        while (cur >= 0) {
+            if (COUNT) { cn.steps++; if (first_active_lane()) cn.wave_steps++; }
+            float4 q0 = geo.node(cur, 0), q1 = geo.node(cur, 1), q2 = geo.node(cur, 2), q3 = geo.node(cur, 3);
             int left = __float_as_int(q3.x), right = __float_as_int(q3.y);
             float tl, tr;
             if (COUNT) cn.box += 2;
@@ -240,22 +266,29 @@ __device__ __forceinline__ void hit_bvh(const DScene& sc, V3 o, const RayN& rn, 
             bool hr = box_test(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, idir, tn_min, best.tn, tr);
             if (hl && hr) {
                 bool left_first = tl <= tr;
-                int near = left_first ? left : right;
-                int far = left_first ? right : left;
-                stack[sp * kBlock] = far;
+                stack[sp * kBlock] = left_first ? right : left;
                 sp++;
-                cur = near;
-                continue;
+                cur = left_first ? left : right;
+            } else if (hl || hr) {
+                cur = hl ? left : right;
+            } else if (sp > 0) {
+                sp--;
+                cur = stack[sp * kBlock];
+            } else {
+                cur = kTravDone;
             }
-            if (hl) { cur = left; continue; }
-            if (hr) { cur = right; continue; }
-        } else {
-            int code = ~cur;
-            leaf_spheres<COUNT>(sc, code >> 2, (code & 3) + 1, o, dh, tn_min, best, cn);
         }
-        if (sp == 0) break;
-        sp--;
-        cur = stack[sp * kBlock];
+        if (cur != kTravDone) {
+            if (COUNT) { cn.steps++; if (first_active_lane()) cn.wave_steps++; }
+            int code = ~cur;
+            leaf_spheres<COUNT>(geo, code >> 2, (code & 3) + 1, o, dh, tn_min, best, cn);
+            if (sp > 0) {
+                sp--;
+                cur = stack[sp * kBlock];
+            } else {
+                cur = kTravDone;
+            }
+        }
     }
 }
 
@@ -265,8 +298,9 @@ __device__ __forceinline__ Cand closest_hit(const DScene& sc, V3 o, V3 d, float 
     Cand best = no_hit();
     RayN rn = normalise(d, t_min);
     hit_always<COUNT>(sc, o, d, rn, t_min, best, cn);
-    if (sc.use_bvh) hit_bvh<COUNT>(sc, o, rn, stack, best, cn);
-    else hit_list<COUNT>(sc, o, rn, best, cn);
+    GeoGlobal geo = {sc.nodes, sc.sph, sc.sph_info};
+    if (sc.use_bvh) hit_bvh<COUNT>(sc, geo, o, rn, stack, best, cn);
+    else hit_list<COUNT>(sc, geo, o, rn, best, cn);
     return best;
 }
 
@@ -543,107 +577,163 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
 
 __device__ __forceinline__ unsigned long long clk() { return __builtin_amdgcn_s_memtime(); }
 
-template <bool COUNT, int STACK, bool PROF>
+// Shade one finished closest-hit query: returns true when the path ended (sample complete).
+// L collects the path's radiance: emitted light along the way and the background at the end.
+template <bool COUNT>
+__device__ __forceinline__ bool shade(const DScene& sc, const DRender& rp, const Cand& c, const Key& key, int depth,
+                                      bool refine, V3& o, V3& d, V3& T, V3& L, Counters& cn) {
+    if (c.kind < 0) {
+        L = L + T * background(sc, d);
+        return true;
+    }
+    int mat = c.kind == 0 ? sc.sph_info[c.idx].y : (c.kind == 1 ? sc.wide[c.idx].mat : sc.rects[c.idx].mat);
+    const DMaterial m = sc.mats[mat];
+    Rec r = make_record(sc, c, o, d, refine, m.tex >= 0);
+    V3 att, sd, em;
+    if (COUNT) cn.shade++;
+    bool cont = scatter(sc, m, d, r, key, (uint32_t)depth, att, sd, em);
+    L = L + T * em;
+    T = T * att;
+    o = r.p;
+    d = sd;
+    return !cont || depth >= rp.max_depth;             // main.cc:13-14: the limit ends in black
+}
+
+template <bool LDS>
+struct GeoOf { using type = GeoGlobal; };
+template <>
+struct GeoOf<true> { using type = GeoLds; };
+
+// Copies the BVH and the sphere list into LDS (LDS variant) behind `lds`.
+template <bool LDS>
+__device__ __forceinline__ typename GeoOf<LDS>::type stage_geometry(const DScene& sc, int* lds) {
+    if constexpr (LDS) {
+        float4* nodes = reinterpret_cast<float4*>(lds);
+        float4* sph = nodes + 4 * sc.n_nodes;
+        int* objs = reinterpret_cast<int*>(sph + sc.n_sph);
+        for (int i = threadIdx.x; i < 4 * sc.n_nodes; i += kBlock) nodes[i] = sc.nodes[i];
+        for (int i = threadIdx.x; i < sc.n_sph; i += kBlock) { sph[i] = sc.sph[i]; objs[i] = sc.sph_info[i].x; }
+        GeoLds g = {nodes, sph, objs};
+        return g;
+    } else {
+        GeoGlobal g = {sc.nodes, sc.sph, sc.sph_info};
+        return g;
+    }
+}
+
+// Radiance sums are kept per pixel in LDS as unsigned 32.32 fixed point and added with integer
+// atomics.  Integer addition is associative, so a pixel's sum does not depend on which lane
+// rendered which sample or in what order: that is what lets lanes take samples dynamically, and
+// it makes an image a pure function of (scene, camera, params).  A sample is truncated to
+// 2^-32 (float samples >= 2^-8 are represented exactly), so the sum is also closer to the
+// reference's double accumulation (main.cc:121) than a running float sum would be.
+__device__ __forceinline__ unsigned long long to_fixed(float v) {
+    v = fminf(fmaxf(v, 0.0f), 1.0e9f);                 // also maps NaN to 0
+    float hi = floorf(v);
+    unsigned lo = (unsigned)((v - hi) * 4294967296.0f);
+    return ((unsigned long long)(unsigned)hi << 32) | lo;
+}
+__device__ __forceinline__ float from_fixed(unsigned long long q) { return (float)((double)q * 2.3283064365386963e-10); }
+
+constexpr int kAccumWords = 64 * 3;                    // per wave: 64 pixels x rgb
+
+// One wave renders a tile of P = 64 / lanes_per_pixel pixels, all samples.  The work units
+// (pixel, sample) of the tile are numbered sample-major and handed out dynamically: whenever
+// lanes are free (their path ended) they take the next units, so every trip of the loop traces
+// one ray on all 64 lanes until the tile runs out of samples, whatever the path lengths were.
+// Dynamic LDS: [traversal stack: stack_depth x kBlock ints][accumulators: 4 waves x 192 u64]
+// then, for the LDS-resident variant, [nodes][spheres][list positions].
+template <bool COUNT, bool LDS, bool PROF>
 __global__ __launch_bounds__(kBlock) void render_kernel(DScene sc, DCamera cam, DRender rp, float4* __restrict__ out,
                                                         unsigned long long* __restrict__ counters) {
-    __shared__ int s_stack[STACK * kBlock];
-    int* stack = s_stack + threadIdx.x;
-
+    extern __shared__ __align__(16) int s_dyn[];
+    int* stack = s_dyn + threadIdx.x;
     const int lane = threadIdx.x & 63;
-    const int K = rp.lanes_per_pixel;
-    const int P = 64 / K;                       // pixels per wave
-    const int TW = P < 8 ? P : 8, TH = P / TW;  // wave tile
+    unsigned long long* accum = reinterpret_cast<unsigned long long*>(s_dyn + rp.stack_depth * kBlock) + (threadIdx.x >> 6) * kAccumWords;
+    const auto geo = stage_geometry<LDS>(sc, s_dyn + rp.stack_depth * kBlock + (kBlock / 64) * kAccumWords * 2);
+    accum[lane * 3 + 0] = 0ull; accum[lane * 3 + 1] = 0ull; accum[lane * 3 + 2] = 0ull;
+    __syncthreads();
+
+    const int P = 64 / rp.lanes_per_pixel;             // pixels of this wave's tile
+    const int logP = 31 - __clz(P);
+    const int TW = P < 8 ? P : 8, TH = P / TW;
     const int tiles_x = (rp.width + TW - 1) / TW;
     const int tiles_y = (rp.rows + TH - 1) / TH;
     const long long wave_id = (long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     const bool wave_ok = wave_id < (long long)tiles_x * tiles_y;
-    const int tile_x = (int)(wave_id % tiles_x), tile_y = (int)(wave_id / tiles_x);
-    const int pix = lane & (P - 1), chunk = lane / P;
-    const int x = tile_x * TW + (pix % TW);
-    const int ly = tile_y * TH + (pix / TW);    // row inside this shard's packed rows
-    const int j = (rp.tile_first + (ly / rp.tile_rows) * rp.tile_step) * rp.tile_rows + (ly % rp.tile_rows);
-    const bool valid = wave_ok && x < rp.width && ly < rp.rows && j < rp.height;
-
-    const int s_begin = rp.sample_begin + (int)(((long long)rp.spp * chunk) / K);
-    const int s_end = rp.sample_begin + (int)(((long long)rp.spp * (chunk + 1)) / K);
+    const int x0 = (int)(wave_id % tiles_x) * TW, ly0 = (int)(wave_id / tiles_x) * TH;
 
     Key key;
     key.seed_lo = rp.seed_lo; key.seed_hi = rp.seed_hi;
-    key.pixel = (uint32_t)(j * rp.width + x);
-    key.sample = (uint32_t)s_begin;
-
-    V3 acc = mk(0.0f, 0.0f, 0.0f);
+    key.pixel = 0u; key.sample = 0u;
     unsigned nrays = 0, nsamples = 0;
-    Counters cn = {0, 0, 0, 0, 0, 0};
+    Counters cn = {0, 0, 0, 0, 0, 0, 0, 0};
     const bool refine = (rp.flags & 2u) == 0u;
 
-    int s = s_begin;
-    bool alive = valid && s < s_end && rp.max_depth > 0;
-    bool fresh = true;
-    V3 o = mk(0, 0, 0), d = mk(0, 0, 1), T = mk(1, 1, 1);
-    int depth = 0;
-    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, tq = 0;
-    while (alive) {
+    const unsigned long long total = (wave_ok && rp.max_depth > 0) ? ((unsigned long long)rp.spp << logP) : 0ull;
+    unsigned long long next = 0ull;                    // wave-uniform: first unit not handed out yet
+    bool has = false;                                  // this lane is on a path
+    int q = 0, depth = 0;                              // pixel of the tile, rays traced on the path
+    V3 o = mk(0, 0, 0), d = mk(0, 0, 1), T = mk(1, 1, 1), L = mk(0, 0, 0);
+    unsigned long long ph[5] = {0, 0, 0, 0, 0}, tq = 0;
+    for (;;) {
         if (PROF) tq = clk();
-        if (fresh) {
-            key.sample = (uint32_t)s;
-            camera_ray(cam, rp, key, x, j, o, d);
-            T = mk(1.0f, 1.0f, 1.0f);
-            depth = 0;
-            fresh = false;
-            nsamples++;
+        const unsigned long long need = __ballot(!has);
+        if (need != 0ull && next < total) {
+            const unsigned long long u = next + (unsigned long long)__builtin_amdgcn_mbcnt_hi((unsigned)(need >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)need, 0u));
+            if (!has && u < total) {
+                q = (int)(u & (unsigned long long)(P - 1));
+                const int x = x0 + (q % TW), ly = ly0 + (q / TW);
+                const int j = (rp.tile_first + (ly / rp.tile_rows) * rp.tile_step) * rp.tile_rows + (ly % rp.tile_rows);
+                if (x < rp.width && ly < rp.rows && j < rp.height) {
+                    key.pixel = (uint32_t)(j * rp.width + x);
+                    key.sample = (uint32_t)rp.sample_begin + (uint32_t)(u >> logP);
+                    camera_ray(cam, rp, key, x, j, o, d);
+                    T = mk(1.0f, 1.0f, 1.0f);
+                    L = mk(0.0f, 0.0f, 0.0f);
+                    depth = 0;
+                    nsamples++;
+                    has = true;
+                }
+            }
+            next += (unsigned long long)__popcll(need);
         }
         if (PROF) { unsigned long long t = clk(); ph[0] += t - tq; tq = t; }
-        Cand c = no_hit();
-        RayN rn = normalise(d, rp.t_min);
-        hit_always<COUNT>(sc, o, d, rn, rp.t_min, c, cn);
-        if (PROF) { unsigned long long t = clk(); ph[1] += t - tq; tq = t; }
-        if (sc.use_bvh) hit_bvh<COUNT>(sc, o, rn, stack, c, cn);
-        else hit_list<COUNT>(sc, o, rn, c, cn);
-        if (PROF) { unsigned long long t = clk(); ph[2] += t - tq; tq = t; }
-        nrays++;
-        depth++;
-        bool done;
-        if (c.kind < 0) {
-            acc = acc + T * background(sc, d);
-            done = true;
-        } else {
-            int mat = c.kind == 0 ? sc.sph_info[c.idx].y : (c.kind == 1 ? sc.wide[c.idx].mat : sc.rects[c.idx].mat);
-            const DMaterial m = sc.mats[mat];
-            Rec r = make_record(sc, c, o, d, refine, m.tex >= 0);
-            if (PROF) { unsigned long long t = clk(); ph[3] += t - tq; tq = t; }
-            V3 att, sd, em;
-            if (COUNT) cn.shade++;
-            bool cont = scatter(sc, m, d, r, key, (uint32_t)depth, att, sd, em);
-            acc = acc + T * em;
-            T = T * att;
-            o = r.p;
-            d = sd;
-            done = !cont || depth >= rp.max_depth;     // main.cc:13-14: the limit ends in black
+        if (__ballot(has) == 0ull) {
+            if (next >= total) break;
+            continue;
         }
-        if (done) {
-            s++;
-            fresh = true;
-            alive = s < s_end;
+        if (has) {
+            Cand c = no_hit();
+            RayN rn = normalise(d, rp.t_min);
+            hit_always<COUNT>(sc, o, d, rn, rp.t_min, c, cn);
+            if (PROF) { unsigned long long t = clk(); ph[1] += t - tq; tq = t; }
+            if (sc.use_bvh) hit_bvh<COUNT>(sc, geo, o, rn, stack, c, cn);
+            else hit_list<COUNT>(sc, geo, o, rn, c, cn);
+            if (PROF) { unsigned long long t = clk(); ph[2] += t - tq; tq = t; }
+            nrays++;
+            depth++;
+            if (shade<COUNT>(sc, rp, c, key, depth, refine, o, d, T, L, cn)) {
+                atomicAdd(&accum[q * 3 + 0], to_fixed(L.x));
+                atomicAdd(&accum[q * 3 + 1], to_fixed(L.y));
+                atomicAdd(&accum[q * 3 + 2], to_fixed(L.z));
+                has = false;
+            }
+            if (PROF) { unsigned long long t = clk(); ph[4] += t - tq; tq = t; }
         }
-        if (PROF) { unsigned long long t = clk(); ph[4] += t - tq; tq = t; }
     }
+    __syncthreads();
 
-    // combine the K slices of each pixel in lane order, then one float4 store per pixel
-    V3 total = acc;
-    for (int cidx = 1; cidx < K; cidx++) {
-        int src = pix + cidx * P;
-        total.x += __shfl(acc.x, src, 64);
-        total.y += __shfl(acc.y, src, 64);
-        total.z += __shfl(acc.z, src, 64);
-    }
-    if (valid && chunk == 0) {
-        float a = (float)rp.spp;
-        if (rp.flags & 1u) {
-            float inv = 1.0f / a;
-            total = inv * total;
+    // one float4 store per pixel of the tile
+    if (wave_ok && lane < P) {
+        const int x = x0 + (lane % TW), ly = ly0 + (lane / TW);
+        const int j = (rp.tile_first + (ly / rp.tile_rows) * rp.tile_step) * rp.tile_rows + (ly % rp.tile_rows);
+        if (x < rp.width && ly < rp.rows && j < rp.height) {
+            float a = (float)rp.spp;
+            V3 total_rgb = mk(from_fixed(accum[lane * 3 + 0]), from_fixed(accum[lane * 3 + 1]), from_fixed(accum[lane * 3 + 2]));
+            if (rp.flags & 1u) total_rgb = (1.0f / a) * total_rgb;
+            out[(size_t)ly * rp.width + x] = make_float4(total_rgb.x, total_rgb.y, total_rgb.z, a);
         }
-        out[(size_t)ly * rp.width + x] = make_float4(total.x, total.y, total.z, a);
     }
 
     unsigned long long r_all = wave_sum(nrays), s_all = wave_sum(nsamples);
@@ -651,16 +741,15 @@ __global__ __launch_bounds__(kBlock) void render_kernel(DScene sc, DCamera cam, 
         atomicAdd(&counters[0], r_all);
         atomicAdd(&counters[1], s_all);
     }
-    if (PROF && lane == 0) {
-        // wave-level clocks per phase: camera, always-tested primitives, traversal, record, scatter
-        for (int q = 0; q < 5; q++) atomicAdd(&counters[kNumCounters + q], ph[q]);
-    }
+    if (PROF && lane == 0)
+        for (int k = 0; k < 5; k++) atomicAdd(&counters[kNumCounters + k], ph[k]);
     if (COUNT) {
-        unsigned long long v[6] = {cn.box, cn.sph, cn.sph_hit, cn.rect, cn.wide, cn.shade};
+        unsigned long long v[8] = {cn.box, cn.sph, cn.sph_hit, cn.rect, cn.wide, cn.shade, cn.steps, cn.wave_steps};
 #pragma unroll
-        for (int q = 0; q < 6; q++) {
-            unsigned long long t = wave_sum(v[q]);
-            if (lane == 0 && t) atomicAdd(&counters[2 + q], t);
+        for (int k = 0; k < 8; k++) {
+            unsigned long long t = wave_sum(v[k]);
+            // traversal step counts share the slots of the phase clocks (a different build)
+            if (lane == 0 && t) atomicAdd(&counters[k < 6 ? 2 + k : kNumCounters + (k - 6)], t);
         }
     }
 }
@@ -675,7 +764,7 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(DScene sc, const float* _
     if (i >= n) return;
     V3 o = mk(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]);
     V3 d = mk(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]);
-    Counters cn = {0, 0, 0, 0, 0, 0};
+    Counters cn = {0, 0, 0, 0, 0, 0, 0, 0};
     Cand c = closest_hit<false>(sc, o, d, t_min, stack, cn);
     Hit h;
     if (c.kind < 0) {
@@ -720,17 +809,23 @@ hipError_t launch_render(const DScene& sc, const DCamera& cam, const DRender& rp
     const long long blocks = (tiles + (kBlock / 64) - 1) / (kBlock / 64);
     if (blocks <= 0) return hipSuccess;
     if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-    // the traversal stack holds one entry per BVH level: shallow trees get the small LDS footprint
-    const bool small = sc.bvh_depth + 2 <= kSmallStack;
+    // dynamic LDS: the traversal stack (one entry per BVH level), the per-pixel accumulators and,
+    // when it all fits in a budget that still leaves four workgroups per CU, a copy of the BVH
+    // and the sphere list
+    DRender r = rp;
+    r.stack_depth = sc.use_bvh ? sc.bvh_depth + 2 : 1;
+    size_t lds = (size_t)r.stack_depth * kBlock * sizeof(int) + (size_t)(kBlock / 64) * kAccumWords * sizeof(unsigned long long);
+    const size_t geo_bytes = (size_t)sc.n_nodes * 64 + (size_t)sc.n_sph * 20;
+    const bool in_lds = (rp.flags & 32u) == 0u && sc.n_sph > 0 && lds + geo_bytes <= 40 * 1024;
+    if (in_lds) lds += geo_bytes;
     const bool count = (rp.flags & 4u) != 0u;
-    dim3 grid((unsigned)blocks), block(kBlock);
     const bool prof = (rp.flags & 8u) != 0u;
-    if (prof && small) hipLaunchKernelGGL((render_kernel<false, kSmallStack, true>), grid, block, 0, stream, sc, cam, rp, out, counters);
-    else if (prof) hipLaunchKernelGGL((render_kernel<false, kMaxStack, true>), grid, block, 0, stream, sc, cam, rp, out, counters);
-    else if (count && small) hipLaunchKernelGGL((render_kernel<true, kSmallStack, false>), grid, block, 0, stream, sc, cam, rp, out, counters);
-    else if (count) hipLaunchKernelGGL((render_kernel<true, kMaxStack, false>), grid, block, 0, stream, sc, cam, rp, out, counters);
-    else if (small) hipLaunchKernelGGL((render_kernel<false, kSmallStack, false>), grid, block, 0, stream, sc, cam, rp, out, counters);
-    else hipLaunchKernelGGL((render_kernel<false, kMaxStack, false>), grid, block, 0, stream, sc, cam, rp, out, counters);
+    dim3 grid((unsigned)blocks), block(kBlock);
+#define RT_LAUNCH(KERNEL) hipLaunchKernelGGL(KERNEL, grid, block, lds, stream, sc, cam, r, out, counters)
+    if (prof) { if (in_lds) RT_LAUNCH((render_kernel<false, true, true>)); else RT_LAUNCH((render_kernel<false, false, true>)); }
+    else if (count) { if (in_lds) RT_LAUNCH((render_kernel<true, true, false>)); else RT_LAUNCH((render_kernel<true, false, false>)); }
+    else { if (in_lds) RT_LAUNCH((render_kernel<false, true, false>)); else RT_LAUNCH((render_kernel<false, false, false>)); }
+#undef RT_LAUNCH
     return hipGetLastError();
 }
 

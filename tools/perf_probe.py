@@ -21,11 +21,14 @@ def run(label, reps=3, **kw):
     print(f"{label:28s} min {min(ms):8.2f} ms  {st['rays'] / min(ms) / 1e3:9.1f} Mrays/s  K={st['lanes_per_pixel']}")
     return st
 st = run("default")
+run("no LDS scene", flags=api.RT_FLAG_NO_LDS_SCENE)
+a = c.render_host(P(256, 128, 8, 50, 3)); d2 = c.render_host(P(256, 128, 8, 50, 3, flags=api.RT_FLAG_NO_LDS_SCENE)); print("LDS == HBM scene bit-exact:", np.array_equal(a, d2))
 run("no refine", flags=api.RT_FLAG_NO_REFINE)
 for k in (2, 4, 8):
     run(f"K={k}", lanes_per_pixel=k)
 cst = run("counters", reps=1, flags=api.RT_FLAG_COUNTERS)
 r = cst["rays"]
+print("traversal: lane steps/ray %.2f, wave steps %.3g, lane utilisation %.3f" % (cst["phase_clocks"][0] / r, cst["phase_clocks"][1], cst["phase_clocks"][0] / (64.0 * cst["phase_clocks"][1])))
 print({k: round(v / r, 3) for k, v in cst.items() if k.endswith("tests") or k in ("sphere_hits", "shades", "samples")})
 pst = run("phase clocks", reps=1, flags=api.RT_FLAG_PHASE_CLOCKS)
 pc = np.array(pst["phase_clocks"], dtype=np.float64)
