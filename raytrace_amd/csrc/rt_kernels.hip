@@ -120,7 +120,7 @@ __device__ __forceinline__ bool sphere_test(float4 s, V3 o, V3 dh, float tn_min,
     float l2 = dot(l, l);
     float r2 = s.w * s.w;
     if (!(l2 <= r2)) return false;
-    float thc = sqrtf(r2 - l2);
+    float thc = __builtin_amdgcn_sqrtf(r2 - l2);    // 1 ulp; the winner's root is polished in double
     float root = tca - thc;
     if (!(root >= tn_min && root <= tn_max)) {
         root = tca + thc;
@@ -143,17 +143,31 @@ __device__ __forceinline__ bool rect_test(const DRect& r, V3 o, V3 d, float t_mi
     return true;
 }
 
-// Slab test (cuda/bounding_box.h:18-29) against [tn_min, tn_max]; boxes are padded on the host
-// and the exit distance is widened by a few ulps, so rounding can only add visits.
+// Slab test (cuda/bounding_box.h:18-29) against [tn_min, tn_max] with the per-ray constants
+// idir = 1/d and oid = -o/d, so a plane distance is one fused multiply-add.  Boxes are padded on
+// the host; the exit distance is widened by a few ulps plus `slack` (the rounding error bound of
+// the fused form, proportional to |o/d|), so rounding can only add visits, never lose a hit.
 __device__ __forceinline__ bool box_test(float bx0, float by0, float bz0, float bx1, float by1, float bz1,
-                                         V3 o, V3 idir, float tn_min, float tn_max, float& t_enter) {
-    float tx0 = (bx0 - o.x) * idir.x, tx1 = (bx1 - o.x) * idir.x;
-    float ty0 = (by0 - o.y) * idir.y, ty1 = (by1 - o.y) * idir.y;
-    float tz0 = (bz0 - o.z) * idir.z, tz1 = (bz1 - o.z) * idir.z;
+                                         V3 idir, V3 oid, float slack, float tn_min, float tn_max, float& t_enter) {
+    float tx0 = fmaf(bx0, idir.x, oid.x), tx1 = fmaf(bx1, idir.x, oid.x);
+    float ty0 = fmaf(by0, idir.y, oid.y), ty1 = fmaf(by1, idir.y, oid.y);
+    float tz0 = fmaf(bz0, idir.z, oid.z), tz1 = fmaf(bz1, idir.z, oid.z);
     float tnear = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), tn_min));
     float tfar = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), tn_max));
     t_enter = tnear;
-    return tnear <= tfar * 1.0000005f;
+    return tnear <= fmaf(tfar, 1.0000005f, slack);
+}
+
+// Per-ray constants of the slab test.  A zero direction component gives an infinite reciprocal;
+// its products are +-inf or NaN, which min/max order away from the other axes' planes.
+struct SlabRay { V3 idir, oid; float slack; };
+__device__ __forceinline__ SlabRay slab_ray(V3 o, V3 dh) {
+    SlabRay r;
+    r.idir = mk(__builtin_amdgcn_rcpf(dh.x), __builtin_amdgcn_rcpf(dh.y), __builtin_amdgcn_rcpf(dh.z));
+    r.oid = mk(-o.x * r.idir.x, -o.y * r.idir.y, -o.z * r.idir.z);
+    float big = fmaxf(fmaxf(fabsf(r.oid.x), fabsf(r.oid.y)), fabsf(r.oid.z));
+    r.slack = isfinite(big) ? 4.0e-7f * big : 0.0f;
+    return r;
 }
 
 // Where the traversal reads its geometry from: HBM (through L1/L2), or a copy in LDS that the
@@ -245,25 +259,30 @@ __device__ __forceinline__ void hit_list(const DScene& sc, const G& geo, V3 o, c
 // a leaf, so testing leaves as they come would run the sphere code for a handful of lanes on
 // nearly every trip.  `stack` is this lane's column of the workgroup's LDS traversal stack
 // (entry e at stack[e * kBlock]).
+//
+// The traversal is resumable: (cur, sp) and `best` are its whole state.  With budget > 0 the
+// wave leaves after about that many node steps; lanes whose traversal is not finished
+// (cur != kTravDone) come back later with the same state, so one long ray does not hold the
+// other 63 lanes of the wave.
 constexpr int kTravDone = (int)0x80000000;     // not a leaf code: ~kTravDone >> 2 exceeds any sphere count
 
-template <bool COUNT, class G>
-__device__ __forceinline__ void hit_bvh(const DScene& sc, const G& geo, V3 o, const RayN& rn, int* stack, Cand& best, Counters& cn) {
-    if (sc.root == kNoBvh) return;
+template <bool COUNT, bool SLICED, class G>
+__device__ __forceinline__ void hit_bvh(const G& geo, V3 o, const RayN& rn, int* stack, int budget,
+                                        int& cur, int& sp, Cand& best, Counters& cn) {
     const V3 dh = rn.dh;
     const float tn_min = rn.tn_min;
-    V3 idir = mk(1.0f / dh.x, 1.0f / dh.y, 1.0f / dh.z);
-    int sp = 0;
-    int cur = sc.root;
-    while (cur != kTravDone) {
-        while (cur >= 0) {
+    const SlabRay sr = slab_ray(o, dh);
+    int wave_steps = 0;                            // wave-uniform
+    bool stop = false;
+    while (cur != kTravDone && !stop) {
+        while (cur >= 0 && !stop) {
             if (COUNT) { cn.steps++; if (first_active_lane()) cn.wave_steps++; }
             float4 q0 = geo.node(cur, 0), q1 = geo.node(cur, 1), q2 = geo.node(cur, 2), q3 = geo.node(cur, 3);
             int left = __float_as_int(q3.x), right = __float_as_int(q3.y);
             float tl, tr;
             if (COUNT) cn.box += 2;
-            bool hl = box_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, idir, tn_min, best.tn, tl);
-            bool hr = box_test(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, idir, tn_min, best.tn, tr);
+            bool hl = box_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, sr.idir, sr.oid, sr.slack, tn_min, best.tn, tl);
+            bool hr = box_test(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, sr.idir, sr.oid, sr.slack, tn_min, best.tn, tr);
             if (hl && hr) {
                 bool left_first = tl <= tr;
                 stack[sp * kBlock] = left_first ? right : left;
@@ -277,8 +296,12 @@ __device__ __forceinline__ void hit_bvh(const DScene& sc, const G& geo, V3 o, co
             } else {
                 cur = kTravDone;
             }
+            if constexpr (SLICED) {
+                wave_steps = __builtin_amdgcn_readfirstlane(wave_steps) + 1;
+                stop = wave_steps >= budget;
+            }
         }
-        if (cur != kTravDone) {
+        if (cur < 0 && cur != kTravDone) {
             if (COUNT) { cn.steps++; if (first_active_lane()) cn.wave_steps++; }
             int code = ~cur;
             leaf_spheres<COUNT>(geo, code >> 2, (code & 3) + 1, o, dh, tn_min, best, cn);
@@ -299,8 +322,11 @@ __device__ __forceinline__ Cand closest_hit(const DScene& sc, V3 o, V3 d, float 
     RayN rn = normalise(d, t_min);
     hit_always<COUNT>(sc, o, d, rn, t_min, best, cn);
     GeoGlobal geo = {sc.nodes, sc.sph, sc.sph_info};
-    if (sc.use_bvh) hit_bvh<COUNT>(sc, geo, o, rn, stack, best, cn);
-    else hit_list<COUNT>(sc, geo, o, rn, best, cn);
+    if (!sc.use_bvh) hit_list<COUNT>(sc, geo, o, rn, best, cn);
+    else if (sc.root != kNoBvh) {
+        int cur = sc.root, sp = 0;
+        hit_bvh<COUNT, false>(geo, o, rn, stack, 0, cur, sp, best, cn);
+    }
     return best;
 }
 
@@ -459,8 +485,7 @@ __device__ __forceinline__ uint32_t xo_next(Xo& g) {
 // vec3.h:130-136.  The first rejection attempt of a scatter segment reads words 0,1,2 of the
 // segment's Philox block (first draw z, then y, then x: the argument evaluation order of the
 // reference build, vec3.h:60); later attempts step xoshiro128++ from the block.
-__device__ __forceinline__ V3 in_unit_sphere(const Key& k, uint32_t segment) {
-    uint4 w = philox4x32_10(k.pixel, k.sample, segment, 0u, k.seed_lo, k.seed_hi);
+__device__ __forceinline__ V3 in_unit_sphere(uint4 w) {
     V3 p = mk(pm1(w.z), pm1(w.y), pm1(w.x));
     if (dot(p, p) >= 1.0f) {
         Xo g; g.s0 = w.x; g.s1 = w.y; g.s2 = w.z; g.s3 = w.w;
@@ -479,12 +504,14 @@ __device__ __forceinline__ V3 in_unit_sphere(const Key& k, uint32_t segment) {
 __device__ __forceinline__ V3 reflect(V3 v, V3 n) { return madd(v, -2.0f * dot(v, n), n); }
 
 // Returns true when the path continues along (so, sd).  `emitted` is always written.
-__device__ __forceinline__ bool scatter(const DScene& sc, const DMaterial& m, V3 d, const Rec& r, const Key& k,
-                                        uint32_t segment, V3& att, V3& sd, V3& emitted) {
+// `w` is the Philox block of the path's current scatter segment; `rs` a point in the unit sphere
+// drawn from it (both materials that need one read the same draws, so it is drawn once).
+__device__ __forceinline__ bool scatter(const DScene& sc, const DMaterial& m, V3 d, const Rec& r, uint4 w, V3 rs,
+                                        V3& att, V3& sd, V3& emitted) {
     emitted = mk(0.0f, 0.0f, 0.0f);
     switch (m.type) {
     case 0: {                                          // lambertian, material.h:21-32
-        V3 s = in_unit_sphere(k, segment);
+        V3 s = rs;
         V3 uvec = (1.0f / sqrtf(dot(s, s))) * s;       // vec3.h:139
         V3 dir = r.n + uvec;
         const float thr = 1e-8f;                       // vec3.h:64-68
@@ -496,7 +523,7 @@ __device__ __forceinline__ bool scatter(const DScene& sc, const DMaterial& m, V3
     case 1: {                                          // metal, material.h:42-47
         V3 ud = (1.0f / sqrtf(dot(d, d))) * d;
         V3 refl = reflect(ud, r.n);
-        if (m.fuzz > 0.0f) refl = madd(refl, m.fuzz, in_unit_sphere(k, segment));
+        if (m.fuzz > 0.0f) refl = madd(refl, m.fuzz, rs);
         sd = refl;
         att = mk(m.r, m.g, m.b);
         return dot(sd, r.n) > 0.0f;
@@ -513,7 +540,6 @@ __device__ __forceinline__ bool scatter(const DScene& sc, const DMaterial& m, V3
         float x = 1.0f - cos_theta;
         float x2 = x * x;
         float refl_prob = r0 + (1.0f - r0) * (x2 * x2 * x);
-        uint4 w = philox4x32_10(k.pixel, k.sample, segment, 0u, k.seed_lo, k.seed_hi);
         if (tir || refl_prob > u01(w.x)) {
             sd = reflect(ud, r.n);
         } else {                                       // vec3.h:163-169
@@ -591,7 +617,11 @@ __device__ __forceinline__ bool shade(const DScene& sc, const DRender& rp, const
     Rec r = make_record(sc, c, o, d, refine, m.tex >= 0);
     V3 att, sd, em;
     if (COUNT) cn.shade++;
-    bool cont = scatter(sc, m, d, r, key, (uint32_t)depth, att, sd, em);
+    // one Philox block per scatter segment, shared by whichever material consumes it
+    const uint4 w = philox4x32_10(key.pixel, key.sample, (uint32_t)depth, 0u, key.seed_lo, key.seed_hi);
+    V3 rs = mk(0.0f, 0.0f, 0.0f);
+    if (m.type == 0 || (m.type == 1 && m.fuzz > 0.0f)) rs = in_unit_sphere(w);
+    bool cont = scatter(sc, m, d, r, w, rs, att, sd, em);
     L = L + T * em;
     T = T * att;
     o = r.p;
@@ -643,7 +673,7 @@ constexpr int kAccumWords = 64 * 3;                    // per wave: 64 pixels x 
 // one ray on all 64 lanes until the tile runs out of samples, whatever the path lengths were.
 // Dynamic LDS: [traversal stack: stack_depth x kBlock ints][accumulators: 4 waves x 192 u64]
 // then, for the LDS-resident variant, [nodes][spheres][list positions].
-template <bool COUNT, bool LDS, bool PROF>
+template <bool COUNT, bool LDS, bool PROF, bool SLICED>
 __global__ __launch_bounds__(kBlock) void render_kernel(DScene sc, DCamera cam, DRender rp, float4* __restrict__ out,
                                                         unsigned long long* __restrict__ counters) {
     extern __shared__ __align__(16) int s_dyn[];
@@ -675,6 +705,10 @@ __global__ __launch_bounds__(kBlock) void render_kernel(DScene sc, DCamera cam, 
     bool has = false;                                  // this lane is on a path
     int q = 0, depth = 0;                              // pixel of the tile, rays traced on the path
     V3 o = mk(0, 0, 0), d = mk(0, 0, 1), T = mk(1, 1, 1), L = mk(0, 0, 0);
+    // closest-hit query in progress: candidate so far and traversal position.  cur == kTravDone
+    // on a lane with a path means "ray not started yet".
+    Cand c = no_hit();
+    int cur = kTravDone, sp = 0;
     unsigned long long ph[5] = {0, 0, 0, 0, 0}, tq = 0;
     for (;;) {
         if (PROF) tq = clk();
@@ -704,20 +738,31 @@ __global__ __launch_bounds__(kBlock) void render_kernel(DScene sc, DCamera cam, 
             continue;
         }
         if (has) {
-            Cand c = no_hit();
-            RayN rn = normalise(d, rp.t_min);
-            hit_always<COUNT>(sc, o, d, rn, rp.t_min, c, cn);
+            const RayN rn = normalise(d, rp.t_min);
+            // without time slices a query starts and ends inside one trip: its state is local
+            Cand c_trip = no_hit();
+            int cur_trip = kTravDone, sp_trip = 0;
+            Cand& cq = *(SLICED ? &c : &c_trip);
+            int& curq = *(SLICED ? &cur : &cur_trip);
+            int& spq = *(SLICED ? &sp : &sp_trip);
+            if (curq == kTravDone) {                   // a new ray: always-tested primitives first
+                cq = no_hit();
+                hit_always<COUNT>(sc, o, d, rn, rp.t_min, cq, cn);
+                nrays++;
+                depth++;
+                if (!sc.use_bvh) hit_list<COUNT>(sc, geo, o, rn, cq, cn);
+                else if (sc.root != kNoBvh) { curq = sc.root; spq = 0; }
+            }
             if (PROF) { unsigned long long t = clk(); ph[1] += t - tq; tq = t; }
-            if (sc.use_bvh) hit_bvh<COUNT>(sc, geo, o, rn, stack, c, cn);
-            else hit_list<COUNT>(sc, geo, o, rn, c, cn);
+            if (curq != kTravDone) hit_bvh<COUNT, SLICED>(geo, o, rn, stack, rp.slice, curq, spq, cq, cn);
             if (PROF) { unsigned long long t = clk(); ph[2] += t - tq; tq = t; }
-            nrays++;
-            depth++;
-            if (shade<COUNT>(sc, rp, c, key, depth, refine, o, d, T, L, cn)) {
-                atomicAdd(&accum[q * 3 + 0], to_fixed(L.x));
-                atomicAdd(&accum[q * 3 + 1], to_fixed(L.y));
-                atomicAdd(&accum[q * 3 + 2], to_fixed(L.z));
-                has = false;
+            if (curq == kTravDone) {                   // query finished (else: resumed next trip)
+                if (shade<COUNT>(sc, rp, cq, key, depth, refine, o, d, T, L, cn)) {
+                    atomicAdd(&accum[q * 3 + 0], to_fixed(L.x));
+                    atomicAdd(&accum[q * 3 + 1], to_fixed(L.y));
+                    atomicAdd(&accum[q * 3 + 2], to_fixed(L.z));
+                    has = false;
+                }
             }
             if (PROF) { unsigned long long t = clk(); ph[4] += t - tq; tq = t; }
         }
@@ -821,10 +866,16 @@ hipError_t launch_render(const DScene& sc, const DCamera& cam, const DRender& rp
     const bool count = (rp.flags & 4u) != 0u;
     const bool prof = (rp.flags & 8u) != 0u;
     dim3 grid((unsigned)blocks), block(kBlock);
-#define RT_LAUNCH(KERNEL) hipLaunchKernelGGL(KERNEL, grid, block, lds, stream, sc, cam, r, out, counters)
-    if (prof) { if (in_lds) RT_LAUNCH((render_kernel<false, true, true>)); else RT_LAUNCH((render_kernel<false, false, true>)); }
-    else if (count) { if (in_lds) RT_LAUNCH((render_kernel<true, true, false>)); else RT_LAUNCH((render_kernel<true, false, false>)); }
-    else { if (in_lds) RT_LAUNCH((render_kernel<false, true, false>)); else RT_LAUNCH((render_kernel<false, false, false>)); }
+    // Deep trees (large scenes) have a long-tailed traversal length: there a wave spends at most
+    // `slice` node steps per trip on traversal and unfinished lanes resume on the next trip.
+    if (r.slice < 0) r.slice = sc.bvh_depth > 12 ? 32 : 0;
+    const bool sliced = sc.use_bvh && r.slice > 0;
+#define RT_LAUNCH(...) hipLaunchKernelGGL((render_kernel<__VA_ARGS__>), grid, block, lds, stream, sc, cam, r, out, counters)
+#define RT_LAUNCH_S(C, L, P) do { if (sliced) RT_LAUNCH(C, L, P, true); else RT_LAUNCH(C, L, P, false); } while (0)
+    if (prof) { if (in_lds) RT_LAUNCH_S(false, true, true); else RT_LAUNCH_S(false, false, true); }
+    else if (count) { if (in_lds) RT_LAUNCH_S(true, true, false); else RT_LAUNCH_S(true, false, false); }
+    else { if (in_lds) RT_LAUNCH_S(false, true, false); else RT_LAUNCH_S(false, false, false); }
+#undef RT_LAUNCH_S
 #undef RT_LAUNCH
     return hipGetLastError();
 }

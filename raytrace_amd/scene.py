@@ -477,5 +477,47 @@ def stress_scene(n_spheres=1_000_000, seed=42, image=None):
     return w
 
 
+def stress_flat(n_spheres=1_000_000, seed=42, image=None) -> FlatScene:
+    """stress_scene() flattened directly with numpy (a million Python objects are slow to make):
+    the same spheres, materials and textures, in the same order."""
+    u = _philox_uniforms(n_spheres * 9, seed).reshape(n_spheres, 9)
+    if image is None:
+        image = procedural_image(256, 128)
+    image = np.ascontiguousarray(image, dtype=np.uint8)
+    geom = np.zeros((n_spheres, 6))
+    geom[:, 0] = -500 + 1000 * u[:, 0]
+    geom[:, 1] = 50 * u[:, 1]
+    geom[:, 2] = -500 + 1000 * u[:, 2]
+    geom[:, 3] = 0.1 + 0.4 * u[:, 3]
+    choose = u[:, 4]
+    is_l, is_m = choose < 0.8, (choose >= 0.8) & (choose < 0.95)
+    n_lamb = np.cumsum(is_l)
+    textured = is_l & (n_lamb % 10 == 0)
+    use_chk = textured & ((n_lamb // 10) % 2 == 1)
+    use_img = textured & ~use_chk
+    # materials 0,1,2 = checker lambertian, image lambertian, glass; then one per plain sphere
+    plain = ~(textured | ~(is_l | is_m))
+    prim_mat = np.zeros(n_spheres, np.int32)
+    prim_mat[use_chk], prim_mat[use_img], prim_mat[~(is_l | is_m)] = 0, 1, 2
+    prim_mat[plain] = 3 + np.arange(int(plain.sum()))
+    pl, pm = plain & is_l, plain & is_m
+    mat_type = np.concatenate([[RT_LAMBERTIAN, RT_LAMBERTIAN, RT_DIELECTRIC],
+                               np.where(is_l[plain], RT_LAMBERTIAN, RT_METAL)]).astype(np.int32)
+    param = np.zeros((3 + int(plain.sum()), 5))
+    param[2] = (1, 1, 1, 0, 1.5)
+    lam = np.stack([u[:, 5] * u[:, 6], u[:, 6] * u[:, 7], u[:, 7] * u[:, 8], np.zeros(n_spheres), np.zeros(n_spheres)], 1)
+    met = np.stack([0.5 + 0.5 * u[:, 5], 0.5 + 0.5 * u[:, 6], 0.5 + 0.5 * u[:, 7], 0.5 * u[:, 8], np.zeros(n_spheres)], 1)
+    param[3:] = np.where(is_l[plain][:, None], lam[plain], met[plain])
+    mat_tex = -np.ones(3 + int(plain.sum()), np.int32)
+    mat_tex[0], mat_tex[1] = 2, 3        # textures: 0,1 solid colours of the checker, 2 checker, 3 image
+    return FlatScene(
+        prim_type=np.zeros(n_spheres, np.int32), prim_geom=geom, prim_mat=prim_mat,
+        mat_type=mat_type, mat_param=param, mat_tex=mat_tex,
+        tex_type=np.array([RT_TEX_SOLID, RT_TEX_SOLID, RT_TEX_CHECKER, RT_TEX_IMAGE], np.int32),
+        tex_color=np.array([[0.2, 0.3, 0.1], [0.9, 0.9, 0.9], [0, 0, 0], [0, 0, 0]], np.float64),
+        tex_a=np.array([0, 0, 0, image.shape[1]], np.int32), tex_b=np.array([0, 0, 1, image.shape[0]], np.int32),
+        tex_off=np.zeros(4, np.int64), texels=image.reshape(-1), background=RT_BG_SKY, bg_color=(0.0, 0.0, 0.0))
+
+
 def stress_camera(aspect_ratio):
     return camera((0, 60, -120), (0, 10, 0), (0, 1, 0), 40, aspect_ratio, 0.0, 10.0)
