@@ -665,26 +665,26 @@ __device__ __forceinline__ unsigned long long to_fixed(float v) {
 }
 __device__ __forceinline__ float from_fixed(unsigned long long q) { return (float)((double)q * 2.3283064365386963e-10); }
 
-constexpr int kAccumWords = 64 * 3;                    // per wave: 64 pixels x rgb
 
 // One wave renders a tile of P = 64 / lanes_per_pixel pixels, all samples.  The work units
 // (pixel, sample) of the tile are numbered sample-major and handed out dynamically: whenever
 // lanes are free (their path ended) they take the next units, so every trip of the loop traces
 // one ray on all 64 lanes until the tile runs out of samples, whatever the path lengths were.
-// Dynamic LDS: [traversal stack: stack_depth x kBlock ints][accumulators: 4 waves x 192 u64]
+// Dynamic LDS: [traversal stack: stack_depth x kBlock ints][accumulators: 4 waves x 3P u64]
 // then, for the LDS-resident variant, [nodes][spheres][list positions].
 template <bool COUNT, bool LDS, bool PROF, bool SLICED>
-__global__ __launch_bounds__(kBlock) void render_kernel(DScene sc, DCamera cam, DRender rp, float4* __restrict__ out,
+__global__ __launch_bounds__(kBlock, 5) void render_kernel(DScene sc, DCamera cam, DRender rp, float4* __restrict__ out,
                                                         unsigned long long* __restrict__ counters) {
     extern __shared__ __align__(16) int s_dyn[];
     int* stack = s_dyn + threadIdx.x;
     const int lane = threadIdx.x & 63;
-    unsigned long long* accum = reinterpret_cast<unsigned long long*>(s_dyn + rp.stack_depth * kBlock) + (threadIdx.x >> 6) * kAccumWords;
-    const auto geo = stage_geometry<LDS>(sc, s_dyn + rp.stack_depth * kBlock + (kBlock / 64) * kAccumWords * 2);
-    accum[lane * 3 + 0] = 0ull; accum[lane * 3 + 1] = 0ull; accum[lane * 3 + 2] = 0ull;
+    const int P = 64 / rp.lanes_per_pixel;             // pixels of this wave's tile
+    const int accum_words = 3 * P;                     // per wave: rgb per pixel of the tile
+    unsigned long long* accum = reinterpret_cast<unsigned long long*>(s_dyn + rp.stack_depth * kBlock) + (threadIdx.x >> 6) * accum_words;
+    const auto geo = stage_geometry<LDS>(sc, s_dyn + rp.stack_depth * kBlock + (kBlock / 64) * accum_words * 2);
+    if (lane < P) { accum[lane * 3 + 0] = 0ull; accum[lane * 3 + 1] = 0ull; accum[lane * 3 + 2] = 0ull; }
     __syncthreads();
 
-    const int P = 64 / rp.lanes_per_pixel;             // pixels of this wave's tile
     const int logP = 31 - __clz(P);
     const int TW = P < 8 ? P : 8, TH = P / TW;
     const int tiles_x = (rp.width + TW - 1) / TW;
@@ -858,8 +858,8 @@ hipError_t launch_render(const DScene& sc, const DCamera& cam, const DRender& rp
     // when it all fits in a budget that still leaves four workgroups per CU, a copy of the BVH
     // and the sphere list
     DRender r = rp;
-    r.stack_depth = sc.use_bvh ? sc.bvh_depth + 2 : 1;
-    size_t lds = (size_t)r.stack_depth * kBlock * sizeof(int) + (size_t)(kBlock / 64) * kAccumWords * sizeof(unsigned long long);
+    r.stack_depth = sc.use_bvh ? sc.bvh_depth + 1 : 1;   // one push per inner level at most
+    size_t lds = (size_t)r.stack_depth * kBlock * sizeof(int) + (size_t)(kBlock / 64) * 3 * (64 / rp.lanes_per_pixel) * sizeof(unsigned long long);
     const size_t geo_bytes = (size_t)sc.n_nodes * 64 + (size_t)sc.n_sph * 20;
     const bool in_lds = (rp.flags & 32u) == 0u && sc.n_sph > 0 && lds + geo_bytes <= 40 * 1024;
     if (in_lds) lds += geo_bytes;

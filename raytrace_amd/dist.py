@@ -33,8 +33,14 @@ def gather_frame(shard, height: int, tile_rows: int, rank: int, world: int, dst:
 
     if world == 1:
         return shard[:height]
-    bufs = [torch.empty_like(shard) for _ in range(world)] if rank == dst else None
-    dist.gather(shard, bufs, dst=dst, group=group)
+    try:
+        bufs = [torch.empty_like(shard) for _ in range(world)] if rank == dst else None
+        dist.gather(shard, bufs, dst=dst, group=group)
+    except (RuntimeError, NotImplementedError):
+        # a backend without gather: every rank receives every shard instead
+        flat = torch.empty((world,) + tuple(shard.shape), dtype=shard.dtype, device=shard.device)
+        dist.all_gather_into_tensor(flat, shard, group=group)
+        bufs = list(flat.unbind(0))
     if rank != dst:
         return None
     frame = torch.empty((height,) + tuple(shard.shape[1:]), dtype=shard.dtype, device=shard.device)

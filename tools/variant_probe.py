@@ -1,0 +1,26 @@
+import os, sys, shutil, subprocess
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+code = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, %r)
+import torch
+from raytrace_amd import api, scene as S
+aspect = float(np.float32(16 / 9))
+c = api.Context(0)
+c.upload_scene(S.flatten(S.rtiow_scene())); c.set_camera(**S.rtiow_camera(aspect).desc())
+buf = torch.zeros((1080, 1920, 4), dtype=torch.float32, device="cuda")
+ms = []
+for _ in range(4):
+    c.render(api.Context.params(1920, 1080, 100, 50, 1), buf.data_ptr()); st = c.stats(); ms.append(st["kernel_ms"])
+print("%%s: %%.2f ms %%.0f Mrays/s" %% (os.environ["VARIANT"], min(ms), st["rays"] / min(ms) / 1e3))
+''' % ROOT
+lib = os.path.join(ROOT, "raytrace_amd", "librt_amd.so")
+keep = lib + ".keep"
+shutil.copy(lib, keep)
+try:
+    for v in sorted(os.listdir(os.path.join(ROOT, "build_variants"))):
+        shutil.copy(os.path.join(ROOT, "build_variants", v), lib)
+        subprocess.run([sys.executable, "-c", code], env=dict(os.environ, VARIANT=v), check=False, timeout=120)
+finally:
+    shutil.copy(keep, lib); os.remove(keep)
