@@ -70,6 +70,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--accel", choices=["bvh", "list"], default="bvh")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="gloo: rehearse the N-rank path on fewer GPUs (ranks share devices, shards gathered via host)")
+    ap.add_argument("--check", action="store_true",
+                    help="rank 0 also renders the whole frame alone and compares it bit for bit with the gathered one")
     args = ap.parse_args()
 
     import numpy as np
@@ -82,12 +86,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    torch.cuda.set_device(local_rank)
+    device = local_rank if args.backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group("gloo")
 
-    ctx = api.Context(local_rank)
+    ctx = api.Context(device)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     ctx.upload_scene(S.flatten(S.rtiow_scene()),
                      accel=api.RT_ACCEL_BVH if args.accel == "bvh" else api.RT_ACCEL_LIST)
@@ -105,6 +113,8 @@ def main():
         ctx.render(params, shard.data_ptr())
         if ev:
             ev[1].record()
+        if args.backend == "gloo" and world > 1:
+            return rdist.gather_frame(shard.cpu(), H, TILE_ROWS, rank, world)
         return rdist.gather_frame(shard, H, TILE_ROWS, rank, world)
 
     def fence():
@@ -126,7 +136,8 @@ def main():
 
     st = ctx.stats()                                  # last frame's device counters (all frames equal)
     kernel_ms = sum(a.elapsed_time(b) for a, b in events) / max(args.steps, 1)
-    tot = torch.tensor([dt, float(st["rays"]), kernel_ms], dtype=torch.float64, device="cuda")
+    tot = torch.tensor([dt, float(st["rays"]), kernel_ms], dtype=torch.float64,
+                       device="cuda" if args.backend == "nccl" else "cpu")
     if world > 1:
         mx = tot.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         sm = tot.clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
@@ -141,6 +152,13 @@ def main():
     flops = executed_flops(cst)
     n_prims = 487
     brute = cst["rays"] * (n_prims * F_SPHERE + 70)
+
+    frame_ok = None
+    if args.check and rank == 0:
+        whole = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+        ctx.render(api.Context.params(W, H, SPP, DEPTH, SEED), whole.data_ptr())
+        torch.cuda.synchronize()
+        frame_ok = bool(torch.equal(whole.cpu(), frame.cpu()))
 
     if rank == 0:
         out = {
@@ -163,6 +181,8 @@ def main():
                          "note": "FP32 VALU-bound path (no dense contraction, ~33 MB of HBM writes per frame); "
                                  "achieved = executed algorithmic flops of rank 0's launch / its HIP-event time"},
         }
+        if frame_ok is not None:
+            out["frame_matches_single_gpu"] = frame_ok
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
             out["speedup_vs_cpu_1thread"] = out["value"] / out["cpu_baseline"]["value"]
