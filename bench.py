@@ -34,6 +34,19 @@ def executed_flops(st):
             misses * F_MISS + st["samples"] * F_CAMERA)
 
 
+def measured_traffic():
+    """HBM bytes per render launch from the committed PMC passes (FETCH_SIZE / WRITE_SIZE are
+    collected with rocprofv3 in runs of their own, so they cannot be read inside this process)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "hbm_traffic.json")))
+    if not files:
+        return None
+    try:
+        return json.load(open(files[-1]))["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline():
     """The reference's own main.cc (compiled into oracle/_ref) on one host core, on a bounded
     sample of the same frame: every 4th pixel of every 4th row, 16 spp, glibc rand() like the
@@ -174,7 +187,8 @@ def main():
                        "rays_per_frame": rays_frame, "lanes_per_pixel": st["lanes_per_pixel"]},
             "roofline": {"bound": "valu", "achieved": flops / (kernel_ms * 1e-3) / 1e12,
                          "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": flops / (kernel_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS, "traffic": None,
+                         "frac": flops / (kernel_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS,
+                         "traffic": measured_traffic() if world == 1 and args.accel == "bvh" else None,
                          "kernel": "render_kernel", "kernel_ms": kernel_ms,
                          "flops_per_launch": flops,
                          "bruteforce_equivalent_tflops": brute / (kernel_ms * 1e-3) / 1e12,
