@@ -3,7 +3,7 @@
 487 spheres) at 1920x1080, 100 samples per pixel, depth 50, on N MI355X of one node.
 
 A step is one frame.  With N > 1 (one process per GPU, launched by torch.distributed.run) the
-frame is split into interleaved 8-row tiles, each rank renders its tiles and the partial
+frame is split into interleaved 4-row tiles, each rank renders its tiles and the partial
 framebuffers are gathered on rank 0 over RCCL, inside the timed region.  A ray is one
 closest-hit query (main.cc:18), counted on the device.
 
@@ -18,7 +18,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-W, H, SPP, DEPTH, SEED, TILE_ROWS = 1920, 1080, 100, 50, 1, 8
+W, H, SPP, DEPTH, SEED, TILE_ROWS = 1920, 1080, 100, 50, 1, 4
 PEAK_FP32_TFLOPS = 157.3          # MI355X FP32 vector peak (256 CU x 128 lanes x 2 x 2.4 GHz)
 
 # algorithmic flops per unit of work, fixed constants: sphere test 25 (+24 when a root is

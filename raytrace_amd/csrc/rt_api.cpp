@@ -168,7 +168,7 @@ int validate_render(rt_context* ctx, const rt_render_params* p, rt::DRender* rp)
 }
 
 int do_render(rt_context* ctx, const rt::DRender& rp, float4* out_dev) {
-    RT_HIP(ctx, hipMemsetAsync(ctx->counters, 0, (rt::kNumCounters + rt::kNumPhaseClocks) * sizeof(unsigned long long), ctx->stream));
+    RT_HIP(ctx, hipMemsetAsync(ctx->counters, 0, rt::kNumCounterSlots * sizeof(unsigned long long), ctx->stream));
     RT_HIP(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
     RT_HIP(ctx, rt::launch_render(ctx->scene, ctx->camera, rp, out_dev, ctx->counters, ctx->stream));
     RT_HIP(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
@@ -195,7 +195,7 @@ int rt_create(int device, rt_context** out) {
     if (!ctx) return RT_ERR_INVALID;
     ctx->device = device;
     DeviceGuard g(device);
-    if (hipMalloc((void**)&ctx->counters, (rt::kNumCounters + rt::kNumPhaseClocks) * sizeof(unsigned long long)) != hipSuccess ||
+    if (hipMalloc((void**)&ctx->counters, rt::kNumCounterSlots * sizeof(unsigned long long)) != hipSuccess ||
         hipEventCreate(&ctx->ev_start) != hipSuccess || hipEventCreate(&ctx->ev_stop) != hipSuccess) {
         rt_destroy(ctx);
         return RT_ERR_HIP;

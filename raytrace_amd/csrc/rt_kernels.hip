@@ -682,16 +682,14 @@ __global__ __launch_bounds__(kBlock, 5) void render_kernel(DScene sc, DCamera ca
     const int accum_words = 3 * P;                     // per wave: rgb per pixel of the tile
     unsigned long long* accum = reinterpret_cast<unsigned long long*>(s_dyn + rp.stack_depth * kBlock) + (threadIdx.x >> 6) * accum_words;
     const auto geo = stage_geometry<LDS>(sc, s_dyn + rp.stack_depth * kBlock + (kBlock / 64) * accum_words * 2);
-    if (lane < P) { accum[lane * 3 + 0] = 0ull; accum[lane * 3 + 1] = 0ull; accum[lane * 3 + 2] = 0ull; }
     __syncthreads();
 
     const int logP = 31 - __clz(P);
     const int TW = P < 8 ? P : 8, TH = P / TW;
     const int tiles_x = (rp.width + TW - 1) / TW;
     const int tiles_y = (rp.rows + TH - 1) / TH;
-    const long long wave_id = (long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-    const bool wave_ok = wave_id < (long long)tiles_x * tiles_y;
-    const int x0 = (int)(wave_id % tiles_x) * TW, ly0 = (int)(wave_id / tiles_x) * TH;
+    const unsigned n_tiles = (unsigned)(tiles_x * tiles_y);
+    unsigned* tile_counter = reinterpret_cast<unsigned*>(counters + kNumCounters + kNumPhaseClocks);
 
     Key key;
     key.seed_lo = rp.seed_lo; key.seed_hi = rp.seed_hi;
@@ -699,8 +697,22 @@ __global__ __launch_bounds__(kBlock, 5) void render_kernel(DScene sc, DCamera ca
     unsigned nrays = 0, nsamples = 0;
     Counters cn = {0, 0, 0, 0, 0, 0, 0, 0};
     const bool refine = (rp.flags & 2u) == 0u;
+    unsigned long long ph[5] = {0, 0, 0, 0, 0}, tq = 0;
 
-    const unsigned long long total = (wave_ok && rp.max_depth > 0) ? ((unsigned long long)rp.spp << logP) : 0ull;
+  // Persistent waves: the grid is sized to fill the chip once and every wave keeps drawing
+  // tiles from one device-wide counter until none are left, so the geometry is staged once per
+  // workgroup and light (sky) and heavy tiles balance out across the waves.
+  for (;;) {
+    unsigned tile = 0u;
+    if (lane == 0) tile = atomicAdd(tile_counter, 1u);
+    tile = (unsigned)__builtin_amdgcn_readfirstlane((int)tile);
+    if (tile >= n_tiles) break;
+    const bool wave_ok = true;
+    const int x0 = (int)(tile % (unsigned)tiles_x) * TW, ly0 = (int)(tile / (unsigned)tiles_x) * TH;
+    if (lane < P) { accum[lane * 3 + 0] = 0ull; accum[lane * 3 + 1] = 0ull; accum[lane * 3 + 2] = 0ull; }
+    __builtin_amdgcn_wave_barrier();                   // LDS serves one wave's accesses in issue order
+
+    const unsigned long long total = (rp.max_depth > 0) ? ((unsigned long long)rp.spp << logP) : 0ull;
     unsigned long long next = 0ull;                    // wave-uniform: first unit not handed out yet
     bool has = false;                                  // this lane is on a path
     int q = 0, depth = 0;                              // pixel of the tile, rays traced on the path
@@ -709,7 +721,6 @@ __global__ __launch_bounds__(kBlock, 5) void render_kernel(DScene sc, DCamera ca
     // on a lane with a path means "ray not started yet".
     Cand c = no_hit();
     int cur = kTravDone, sp = 0;
-    unsigned long long ph[5] = {0, 0, 0, 0, 0}, tq = 0;
     for (;;) {
         if (PROF) tq = clk();
         const unsigned long long need = __ballot(!has);
@@ -767,7 +778,7 @@ __global__ __launch_bounds__(kBlock, 5) void render_kernel(DScene sc, DCamera ca
             if (PROF) { unsigned long long t = clk(); ph[4] += t - tq; tq = t; }
         }
     }
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
 
     // one float4 store per pixel of the tile
     if (wave_ok && lane < P) {
@@ -780,6 +791,8 @@ __global__ __launch_bounds__(kBlock, 5) void render_kernel(DScene sc, DCamera ca
             out[(size_t)ly * rp.width + x] = make_float4(total_rgb.x, total_rgb.y, total_rgb.z, a);
         }
     }
+    __builtin_amdgcn_wave_barrier();
+  }  // next tile
 
     unsigned long long r_all = wave_sum(nrays), s_all = wave_sum(nsamples);
     if (lane == 0 && r_all) {
@@ -851,9 +864,12 @@ hipError_t launch_render(const DScene& sc, const DCamera& cam, const DRender& rp
     const int P = 64 / K;
     const int TW = P < 8 ? P : 8, TH = P / TW;
     const long long tiles = (long long)((rp.width + TW - 1) / TW) * ((rp.rows + TH - 1) / TH);
-    const long long blocks = (tiles + (kBlock / 64) - 1) / (kBlock / 64);
-    if (blocks <= 0) return hipSuccess;
-    if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    if (tiles <= 0) return hipSuccess;
+    if (tiles > 0x7fffffffLL) return hipErrorInvalidValue;
+    // persistent waves: enough workgroups to fill 256 CUs at the kernel's occupancy
+    // (5 workgroups per CU), never more than there are tiles
+    long long blocks = (tiles + (kBlock / 64) - 1) / (kBlock / 64);
+    if (blocks > 256 * 5) blocks = 256 * 5;
     // dynamic LDS: the traversal stack (one entry per BVH level), the per-pixel accumulators and,
     // when it all fits in a budget that still leaves four workgroups per CU, a copy of the BVH
     // and the sphere list

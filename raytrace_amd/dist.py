@@ -25,6 +25,17 @@ def max_shard_rows(height: int, tile_rows: int, world: int) -> int:
     return max(len(shard_row_map(height, tile_rows, g, world)) for g in range(world))
 
 
+_ROW_INDEX_CACHE = {}
+
+
+def _row_index(height, tile_rows, g, world, device):
+    import torch
+    key = (height, tile_rows, g, world, str(device))
+    if key not in _ROW_INDEX_CACHE:
+        _ROW_INDEX_CACHE[key] = torch.as_tensor(shard_row_map(height, tile_rows, g, world), device=device)
+    return _ROW_INDEX_CACHE[key]
+
+
 def gather_frame(shard, height: int, tile_rows: int, rank: int, world: int, dst: int = 0, group=None):
     """shard: torch tensor [max_shard_rows, W, C] (rows past this rank's count are padding).
     Returns the assembled [height, W, C] frame on `dst`, None elsewhere."""
@@ -45,7 +56,7 @@ def gather_frame(shard, height: int, tile_rows: int, rank: int, world: int, dst:
         return None
     frame = torch.empty((height,) + tuple(shard.shape[1:]), dtype=shard.dtype, device=shard.device)
     for g in range(world):
-        rows = torch.as_tensor(shard_row_map(height, tile_rows, g, world), device=shard.device)
+        rows = _row_index(height, tile_rows, g, world, shard.device)
         frame[rows] = bufs[g][: rows.numel()]
     return frame
 
