@@ -91,7 +91,7 @@ struct DRender {
 // [5] rect tests, [6] wide tests, [7] shades
 constexpr int kNumCounters = 8;
 constexpr int kNumPhaseClocks = 5;         // extra slots behind the counters (diagnostic build)
-constexpr int kNumCounterSlots = kNumCounters + kNumPhaseClocks + 1;   // + the tile counter of the persistent waves
+constexpr int kNumCounterSlots = kNumCounters + kNumPhaseClocks + 4;   // + eight 32-bit tile counters of the persistent waves
 constexpr int kNoBvh = 0x7fffffff;
 constexpr int kMaxStack = 48;               // deepest BVH the traversal stack holds
 

@@ -702,10 +702,24 @@ __global__ __launch_bounds__(kBlock, 5) void render_kernel(DScene sc, DCamera ca
   // Persistent waves: the grid is sized to fill the chip once and every wave keeps drawing
   // tiles from one device-wide counter until none are left, so the geometry is staged once per
   // workgroup and light (sky) and heavy tiles balance out across the waves.
+  constexpr int kBands = LDS ? 1 : 8;
+  int band = LDS ? 0 : (int)(__builtin_amdgcn_s_getreg(6164) & 7u), bands_tried = 0;   // HW_REG_XCC_ID[3:0]
   for (;;) {
-    unsigned tile = 0u;
-    if (lane == 0) tile = atomicAdd(tile_counter, 1u);
-    tile = (unsigned)__builtin_amdgcn_readfirstlane((int)tile);
+    // Tiles are dealt in eight contiguous bands, one per XCD (each XCD has its own L2, so the rays
+    // of one band keep re-using the BVH nodes that XCD has cached); a wave whose band has run
+    // out helps with the next one.
+    // With the geometry in LDS there is nothing to re-use in L2 and one band (bottom rows, the
+    // heaviest, first) leaves the shortest tail.
+    unsigned tile = n_tiles;
+    while (bands_tried < kBands) {
+        const unsigned b0 = (unsigned)(((unsigned long long)n_tiles * band) / kBands), b1 = (unsigned)(((unsigned long long)n_tiles * (band + 1)) / kBands);
+        unsigned t = 0u;
+        if (lane == 0) t = atomicAdd(tile_counter + band, 1u);
+        t = (unsigned)__builtin_amdgcn_readfirstlane((int)t);
+        if (b0 + t < b1) { tile = b0 + t; break; }
+        band = (band + 1) % kBands;
+        bands_tried++;
+    }
     if (tile >= n_tiles) break;
     const bool wave_ok = true;
     const int x0 = (int)(tile % (unsigned)tiles_x) * TW, ly0 = (int)(tile / (unsigned)tiles_x) * TH;

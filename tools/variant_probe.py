@@ -8,12 +8,17 @@ import torch
 from raytrace_amd import api, scene as S
 aspect = float(np.float32(16 / 9))
 c = api.Context(0)
+buf = torch.zeros((2160, 3840, 4), dtype=torch.float32, device="cuda")
+def run(label, W, H, spp):
+    ms = []
+    for _ in range(3):
+        c.render(api.Context.params(W, H, spp, 50, 1), buf.data_ptr()); st = c.stats(); ms.append(st["kernel_ms"])
+    print("%%s %%s: %%.2f ms %%.0f Mrays/s" %% (os.environ["VARIANT"], label, min(ms), st["rays"] / min(ms) / 1e3), flush=True)
 c.upload_scene(S.flatten(S.rtiow_scene())); c.set_camera(**S.rtiow_camera(aspect).desc())
-buf = torch.zeros((1080, 1920, 4), dtype=torch.float32, device="cuda")
-ms = []
-for _ in range(4):
-    c.render(api.Context.params(1920, 1080, 100, 50, 1), buf.data_ptr()); st = c.stats(); ms.append(st["kernel_ms"])
-print("%%s: %%.2f ms %%.0f Mrays/s" %% (os.environ["VARIANT"], min(ms), st["rays"] / min(ms) / 1e3))
+run("C2", 1920, 1080, 100)
+if os.environ.get("WITH_C4"):
+    c.upload_scene(S.stress_flat(1000000), accel=api.RT_ACCEL_BVH); c.set_camera(**S.stress_camera(aspect).desc())
+    run("C4@16", 3840, 2160, 16)
 ''' % ROOT
 lib = os.path.join(ROOT, "raytrace_amd", "librt_amd.so")
 keep = lib + ".keep"
@@ -21,6 +26,6 @@ shutil.copy(lib, keep)
 try:
     for v in sorted(os.listdir(os.path.join(ROOT, "build_variants"))):
         shutil.copy(os.path.join(ROOT, "build_variants", v), lib)
-        subprocess.run([sys.executable, "-c", code], env=dict(os.environ, VARIANT=v), check=False, timeout=120)
+        subprocess.run([sys.executable, "-c", code], env=dict(os.environ, VARIANT=v), check=False, timeout=300)
 finally:
     shutil.copy(keep, lib); os.remove(keep)
