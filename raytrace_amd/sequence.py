@@ -1,0 +1,92 @@
+"""Multi-frame camera-path driver: the frame loop of the reference's CUDA host program
+(cuda/main.cu:557-591) on the GPU path, plus the post-processing its helper scripts shell out for.
+
+    for frame: update_scene (cuda/main.cu:220-279) -> render -> write_color -> image_<frame>_low.ppm
+
+`render_sequence` writes P3 text like the reference (cuda/main.cu:358-383, with color.h's clamp),
+binary P6, or PNG directly, which replaces cuda/output/convert.py (ImageMagick per file).
+`encode_video` is cuda/output/generate_video.py: the same ffmpeg command line, run only when
+ffmpeg exists.  With several ranks (one process per GPU) frames are dealt round-robin: frames are
+independent, so there is nothing to exchange.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import struct
+import subprocess
+import zlib
+
+import numpy as np
+
+from . import ppm
+from . import scene as S
+
+
+def png_bytes(rgb8_bottom_up: np.ndarray) -> bytes:
+    """Minimal PNG encoder (8-bit RGB, no filtering): rows top to bottom."""
+    h, w, _ = rgb8_bottom_up.shape
+    rows = np.ascontiguousarray(rgb8_bottom_up[::-1]).reshape(h, w * 3)
+    raw = np.concatenate([np.zeros((h, 1), np.uint8), rows], axis=1).tobytes()
+
+    def chunk(tag, data):
+        body = tag + data
+        return struct.pack(">I", len(data)) + body + struct.pack(">I", zlib.crc32(body) & 0xFFFFFFFF)
+
+    return (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 0)) +
+            chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
+
+
+def frame_path(out_dir: str, frame: int, fmt: str, quality: str = "low") -> str:
+    if fmt == "png":
+        # cuda/output/convert.py:17-30 -> png_images/<quality>/image_<n>.png
+        return os.path.join(out_dir, "png_images", quality, f"image_{frame}.png")
+    return os.path.join(out_dir, "ppm_images", ppm.frame_name(frame, quality))   # cuda/main.cu:569
+
+
+def render_sequence(ctx, cam: S.camera, frames, width: int, height: int, spp: int, out_dir: str | None,
+                    max_depth: int = 25, seed: int = 1, fmt: str = "p3", quality: str = "low",
+                    rank: int = 0, world: int = 1, first_frame: int = 0):
+    """Renders frames first_frame .. first_frame+frames-1 of the camera path that starts at `cam`.
+    Every rank advances the camera through all frames (cheap, host) and renders those with
+    frame % world == rank.  Returns [(frame, rays, kernel_ms)] of the frames this rank rendered."""
+    import torch
+
+    from . import api
+
+    fb = torch.zeros((height, width, 4), dtype=torch.float32, device=f"cuda:{ctx.device}")
+    rgb8 = torch.zeros((height, width, 3), dtype=torch.uint8, device=f"cuda:{ctx.device}")
+    done = []
+    for frame in range(first_frame + frames):
+        S.update_scene(cam, frame)                              # cuda/main.cu:564
+        if frame < first_frame or frame % world != rank:
+            continue
+        ctx.set_camera(**cam.desc())
+        ctx.render(api.Context.params(width, height, spp, max_depth, seed=seed + frame), fb.data_ptr())
+        ctx.quantize(fb.data_ptr(), width * height, spp, rgb8.data_ptr())
+        st = ctx.stats()
+        img = rgb8.cpu().numpy()
+        if out_dir is not None:
+            path = frame_path(out_dir, frame, fmt, quality)
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            if fmt == "p3":
+                ppm.write_p3(path, img)
+            elif fmt == "p6":
+                ppm.write_p6(path, img)
+            elif fmt == "png":
+                with open(path, "wb") as f:
+                    f.write(png_bytes(img))
+            else:
+                raise ValueError(f"unknown format {fmt!r}")
+        done.append((frame, st["rays"], st["kernel_ms"]))
+    return done
+
+
+def encode_video(out_dir: str, fps: int = 60, quality: str = "low", name: str = "render_video.mp4"):
+    """cuda/output/generate_video.py:2-12.  Returns the command; runs it only when ffmpeg exists."""
+    cmd = ["ffmpeg", "-r", str(fps), "-i", os.path.join(out_dir, "png_images", quality, "image_%01d.png"),
+           "-c:v", "libx264", "-crf", "20", "-pix_fmt", "yuv420p", os.path.join(out_dir, name)]
+    if shutil.which("ffmpeg"):
+        subprocess.run(cmd, check=True)
+        return cmd, True
+    return cmd, False
