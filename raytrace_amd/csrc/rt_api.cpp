@@ -345,9 +345,10 @@ int rt_upload_scene(rt_context* ctx, const rt_scene_desc* d) {
         if (bvh.depth > rt::kMaxStack - 2) return fail(ctx, RT_ERR_UNSUPPORTED, "BVH deeper than the traversal stack");
         order = bvh.order;
     }
-    std::vector<float4> sph((size_t)ns);
-    std::vector<double4> sph64((size_t)ns);
-    std::vector<int2> info((size_t)ns);
+    const int64_t ns_pad = (ns + 3) / 4 * 4;
+    std::vector<float4> sph((size_t)ns_pad, make_float4(1e30f, 1e30f, 1e30f, 0.0f));
+    std::vector<double4> sph64((size_t)ns_pad, make_double4(1e30, 1e30, 1e30, 1.0));
+    std::vector<int2> info((size_t)ns_pad, make_int2(-1, 0));
     for (int64_t k = 0; k < ns; k++) {
         int32_t i = order[k];
         sph[k] = make_float4((float)sc_c[3 * i], (float)sc_c[3 * i + 1], (float)sc_c[3 * i + 2], (float)std::fabs(sc_r[i]));
@@ -373,6 +374,7 @@ int rt_upload_scene(rt_context* ctx, const rt_scene_desc* d) {
         return rc;
     }
     s.n_sph = (int)ns;
+    s.n_sph_padded = (int)ns_pad;
     s.n_nodes = (int)(bvh.nodes.size() / 16);
     s.root = use_bvh ? bvh.root : rt::kNoBvh;
     s.bvh_depth = bvh.depth;

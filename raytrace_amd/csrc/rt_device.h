@@ -48,6 +48,7 @@ struct DScene {
     const double4* sph64;
     const int2* sph_info;
     int n_sph;
+    int n_sph_padded;     // sph / sph_info hold this many records (multiple of 4; the padding cannot be hit)
     const float4* nodes;
     int n_nodes;
     int root;             // inner index, leaf code, or kNoBvh

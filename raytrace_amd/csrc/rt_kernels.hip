@@ -247,10 +247,50 @@ __device__ __forceinline__ void hit_always(const DScene& sc, V3 o, V3 d, const R
     }
 }
 
-// sceneobject_list.h:26-39: every ordinary sphere, in list order.
-template <bool COUNT, class G>
-__device__ __forceinline__ void hit_list(const DScene& sc, const G& geo, V3 o, const RayN& rn, Cand& best, Counters& cn) {
-    leaf_spheres<COUNT>(geo, 0, sc.n_sph, o, rn.dh, rn.tn_min, best, cn);
+// sceneobject_list.h:26-39: every ordinary sphere, in list order.  The sphere index is the same
+// in all lanes, so the records arrive through scalar loads and sit in SGPRs; four spheres are
+// screened per trip with the branch-free part of the test (is the centre closer to the ray's
+// line than the radius?) and only a group in which some lane passes runs the full test.  The
+// array is padded to a multiple of four with spheres nothing can hit.
+template <bool COUNT>
+__device__ __forceinline__ void hit_list(const DScene& sc, V3 o, const RayN& rn, Cand& best, Counters& cn) {
+    // constant address space: tells the compiler nothing in the kernel writes these records, which
+    // is what it needs to fetch them with scalar loads
+    typedef const float __attribute__((address_space(4))) cfloat;
+    typedef const int __attribute__((address_space(4))) cint;
+    const cfloat* sph = (const cfloat*)(unsigned long long)sc.sph;
+    const cint* info = (const cint*)(unsigned long long)sc.sph_info;
+    const V3 dh = rn.dh;
+    for (int i = 0; i < sc.n_sph_padded; i += 4) {
+        float tca[4], gap[4];                          // gap = r^2 - (distance of the centre from the line)^2
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float sx = sph[4 * (i + k)], sy = sph[4 * (i + k) + 1], sz = sph[4 * (i + k) + 2], sr = sph[4 * (i + k) + 3];
+            V3 L = mk(sx - o.x, sy - o.y, sz - o.z);
+            tca[k] = dot(L, dh);
+            V3 l = madd(L, -tca[k], dh);
+            gap[k] = fmaf(sr, sr, -dot(l, l));
+        }
+        if (COUNT) cn.sph += 4;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            // wave-uniform branch: skipped when no lane's line comes within the radius; inside,
+            // the rest of sphere_test without branches.  The scan runs in list order, so "later
+            // object wins an exact tie" is simply "accept when root <= closest so far".
+            if (__ballot(gap[k] >= 0.0f) != 0ull) {
+                float thc = __builtin_amdgcn_sqrtf(fmaxf(gap[k], 0.0f));
+                float t0 = tca[k] - thc, t1 = tca[k] + thc;
+                bool ok0 = t0 >= rn.tn_min && t0 <= best.tn;
+                bool ok1 = t1 >= rn.tn_min && t1 <= best.tn;
+                bool hit = gap[k] >= 0.0f && (ok0 || ok1);
+                if (COUNT && hit) cn.sph_hit++;
+                best.tn = hit ? (ok0 ? t0 : t1) : best.tn;
+                best.idx = hit ? i + k : best.idx;
+                best.kind = hit ? 0 : best.kind;
+                best.obj = hit ? info[2 * (i + k)] : best.obj;
+            }
+        }
+    }
 }
 
 // BVH traversal, near child first, as two nested loops: the inner one walks inner nodes until
@@ -322,7 +362,7 @@ __device__ __forceinline__ Cand closest_hit(const DScene& sc, V3 o, V3 d, float 
     RayN rn = normalise(d, t_min);
     hit_always<COUNT>(sc, o, d, rn, t_min, best, cn);
     GeoGlobal geo = {sc.nodes, sc.sph, sc.sph_info};
-    if (!sc.use_bvh) hit_list<COUNT>(sc, geo, o, rn, best, cn);
+    if (!sc.use_bvh) hit_list<COUNT>(sc, o, rn, best, cn);
     else if (sc.root != kNoBvh) {
         int cur = sc.root, sp = 0;
         hit_bvh<COUNT, false>(geo, o, rn, stack, 0, cur, sp, best, cn);
@@ -506,7 +546,7 @@ __device__ __forceinline__ V3 reflect(V3 v, V3 n) { return madd(v, -2.0f * dot(v
 // Returns true when the path continues along (so, sd).  `emitted` is always written.
 // `w` is the Philox block of the path's current scatter segment; `rs` a point in the unit sphere
 // drawn from it (both materials that need one read the same draws, so it is drawn once).
-__device__ __forceinline__ bool scatter(const DScene& sc, const DMaterial& m, V3 d, const Rec& r, uint4 w, V3 rs,
+__device__ __forceinline__ bool scatter(const DScene& sc, const DMaterial& m, V3 ud, const Rec& r, uint4 w, V3 rs,
                                         V3& att, V3& sd, V3& emitted) {
     emitted = mk(0.0f, 0.0f, 0.0f);
     switch (m.type) {
@@ -521,8 +561,7 @@ __device__ __forceinline__ bool scatter(const DScene& sc, const DMaterial& m, V3
         return true;
     }
     case 1: {                                          // metal, material.h:42-47
-        V3 ud = (1.0f / sqrtf(dot(d, d))) * d;
-        V3 refl = reflect(ud, r.n);
+        V3 refl = reflect(ud, r.n);                    // ud = unit_vector(r_in.direction())
         if (m.fuzz > 0.0f) refl = madd(refl, m.fuzz, rs);
         sd = refl;
         att = mk(m.r, m.g, m.b);
@@ -531,7 +570,6 @@ __device__ __forceinline__ bool scatter(const DScene& sc, const DMaterial& m, V3
     case 2: {                                          // dielectric, material.h:58-91
         att = mk(1.0f, 1.0f, 1.0f);
         float ratio = r.front ? (1.0f / m.ir) : m.ir;
-        V3 ud = (1.0f / sqrtf(dot(d, d))) * d;
         float cos_theta = fminf(dot(-ud, r.n), 1.0f);
         float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
         bool tir = ratio * sin_theta > 1.0f;
@@ -584,9 +622,9 @@ __device__ __forceinline__ void camera_ray(const DCamera& cam, const DRender& rp
 }
 
 // main.cc:30-34
-__device__ __forceinline__ V3 background(const DScene& sc, V3 d) {
+__device__ __forceinline__ V3 background(const DScene& sc, V3 ud) {      // ud: unit direction
     if (sc.background == 0) {
-        float y = d.y * (1.0f / sqrtf(dot(d, d)));
+        float y = ud.y;
         float t = 0.5f * (y + 1.0f);
         return mk(fmaf(t, 0.5f, 1.0f - t), fmaf(t, 0.7f, 1.0f - t), fmaf(t, 1.0f, 1.0f - t));
     }
@@ -607,9 +645,9 @@ __device__ __forceinline__ unsigned long long clk() { return __builtin_amdgcn_s_
 // L collects the path's radiance: emitted light along the way and the background at the end.
 template <bool COUNT>
 __device__ __forceinline__ bool shade(const DScene& sc, const DRender& rp, const Cand& c, const Key& key, int depth,
-                                      bool refine, V3& o, V3& d, V3& T, V3& L, Counters& cn) {
+                                      bool refine, const RayN& rn, V3& o, V3& d, V3& T, V3& L, Counters& cn) {
     if (c.kind < 0) {
-        L = L + T * background(sc, d);
+        L = L + T * background(sc, rn.dh);
         return true;
     }
     int mat = c.kind == 0 ? sc.sph_info[c.idx].y : (c.kind == 1 ? sc.wide[c.idx].mat : sc.rects[c.idx].mat);
@@ -621,7 +659,7 @@ __device__ __forceinline__ bool shade(const DScene& sc, const DRender& rp, const
     const uint4 w = philox4x32_10(key.pixel, key.sample, (uint32_t)depth, 0u, key.seed_lo, key.seed_hi);
     V3 rs = mk(0.0f, 0.0f, 0.0f);
     if (m.type == 0 || (m.type == 1 && m.fuzz > 0.0f)) rs = in_unit_sphere(w);
-    bool cont = scatter(sc, m, d, r, w, rs, att, sd, em);
+    bool cont = scatter(sc, m, rn.dh, r, w, rs, att, sd, em);
     L = L + T * em;
     T = T * att;
     o = r.p;
@@ -775,14 +813,14 @@ __global__ __launch_bounds__(kBlock, 5) void render_kernel(DScene sc, DCamera ca
                 hit_always<COUNT>(sc, o, d, rn, rp.t_min, cq, cn);
                 nrays++;
                 depth++;
-                if (!sc.use_bvh) hit_list<COUNT>(sc, geo, o, rn, cq, cn);
+                if (!sc.use_bvh) hit_list<COUNT>(sc, o, rn, cq, cn);
                 else if (sc.root != kNoBvh) { curq = sc.root; spq = 0; }
             }
             if (PROF) { unsigned long long t = clk(); ph[1] += t - tq; tq = t; }
             if (curq != kTravDone) hit_bvh<COUNT, SLICED>(geo, o, rn, stack, rp.slice, curq, spq, cq, cn);
             if (PROF) { unsigned long long t = clk(); ph[2] += t - tq; tq = t; }
             if (curq == kTravDone) {                   // query finished (else: resumed next trip)
-                if (shade<COUNT>(sc, rp, cq, key, depth, refine, o, d, T, L, cn)) {
+                if (shade<COUNT>(sc, rp, cq, key, depth, refine, rn, o, d, T, L, cn)) {
                     atomicAdd(&accum[q * 3 + 0], to_fixed(L.x));
                     atomicAdd(&accum[q * 3 + 1], to_fixed(L.y));
                     atomicAdd(&accum[q * 3 + 2], to_fixed(L.z));
@@ -891,7 +929,7 @@ hipError_t launch_render(const DScene& sc, const DCamera& cam, const DRender& rp
     r.stack_depth = sc.use_bvh ? sc.bvh_depth + 1 : 1;   // one push per inner level at most
     size_t lds = (size_t)r.stack_depth * kBlock * sizeof(int) + (size_t)(kBlock / 64) * 3 * (64 / rp.lanes_per_pixel) * sizeof(unsigned long long);
     const size_t geo_bytes = (size_t)sc.n_nodes * 64 + (size_t)sc.n_sph * 20;
-    const bool in_lds = (rp.flags & 32u) == 0u && sc.n_sph > 0 && lds + geo_bytes <= 40 * 1024;
+    const bool in_lds = (rp.flags & 32u) == 0u && sc.use_bvh && sc.n_sph > 0 && lds + geo_bytes <= 40 * 1024;
     if (in_lds) lds += geo_bytes;
     const bool count = (rp.flags & 4u) != 0u;
     const bool prof = (rp.flags & 8u) != 0u;
