@@ -8,6 +8,7 @@
  *   ---------------------------------------------------   -------------------------
  *   create_world<<<1,1>>>        cuda/main.cu:39-189,520   rt_upload_scene
  *   load_texture (H2D part)      cuda/main.cu:385-436      rt_upload_scene (texels)
+ *   rotate_y wrappers            cuda/sceneobject.h:31-109 rt_upload_scene (xform, prim_xform)
  *   camera ctor / update_scene   camera.h:19-38,
  *                                cuda/main.cu:220-279,564  rt_set_camera
  *   init_render + render<<<>>>   cuda/main.cu:281-355,582  rt_render / rt_render_host
@@ -82,6 +83,13 @@ typedef struct rt_scene_desc {
     int32_t accel;               /* RT_ACCEL_* */
     double wide_radius;          /* spheres with a larger radius are intersected in double
                                     (0 = default 64.0) */
+    /* Instance transforms (cuda/sceneobject.h:31-109 rotate_y, plus a translation): primitive i
+     * with prim_xform[i] = x >= 0 stands at  world = R_y(angle_x) * object + offset_x ; -1 (or a
+     * NULL prim_xform) leaves it where its geometry says.  Nested wrappers compose into this one
+     * form on the caller's side.  A descriptor whose struct_size ends before n_xforms has none. */
+    int32_t n_xforms;
+    const double* xform;         /* [n_xforms][4] angle in degrees about +y, offset x y z */
+    const int32_t* prim_xform;   /* [n_prims] or NULL */
 } rt_scene_desc;
 
 /* camera.h:19-20 argument list */

@@ -8,6 +8,7 @@
 //   xy_rect / xz_rect / yz_rect(a0,a1,b0,b1,k,m)  cuda/rect.h:19,66,112
 //   sceneobject_list::add / clear                 sceneobject_list.h:16-21
 //   bvh_node(list)                                cuda/bvh.h:18
+//   rotate_y(object, angle)                       cuda/sceneobject.h:31-47 (+ translate, box)
 //   lambertian / metal / dielectric               material.h:19,40,56
 //   lambertian_bg / diffuse_light                 cuda/material.h:37-38,107-109
 //   rgb_color / checker_texture / image_texture   cuda/texture.h:22,39-41,61
@@ -18,6 +19,7 @@
 #ifndef RT_SCENE_HPP
 #define RT_SCENE_HPP
 
+#include <cmath>
 #include <cstdint>
 #include <map>
 #include <memory>
@@ -117,6 +119,28 @@ struct bvh_node : sceneobject_list {
     explicit bvh_node(const sceneobject_list& l) { objects = l.objects; }
 };
 
+// cuda/sceneobject.h:31-47: `p` turned by `angle` degrees about the world's +y axis.
+struct rotate_y : sceneobject {
+    shared_ptr<sceneobject> ptr; double angle;
+    rotate_y(shared_ptr<sceneobject> p, double angle_) : ptr(p), angle(angle_) {}
+};
+// `p` moved by `displacement` (the companion every use of rotate_y needs: an object turns about
+// the world's y axis, not its own).
+struct translate : sceneobject {
+    shared_ptr<sceneobject> ptr; vec3 offset;
+    translate(shared_ptr<sceneobject> p, vec3 displacement) : ptr(p), offset(displacement) {}
+};
+// The six rects of an axis-aligned box in the order of cuda/main.cu:130-137: per axis pair the
+// face at p1 first (material `m`), then the face at p0 (`m_low`, default `m`).
+inline shared_ptr<sceneobject_list> box(point3 p0, point3 p1, shared_ptr<material> m, shared_ptr<material> m_low = nullptr) {
+    if (!m_low) m_low = m;
+    auto l = make_shared<sceneobject_list>();
+    l->add(make_shared<xy_rect>(p0.x(), p1.x(), p0.y(), p1.y(), p1.z(), m)); l->add(make_shared<xy_rect>(p0.x(), p1.x(), p0.y(), p1.y(), p0.z(), m_low));
+    l->add(make_shared<xz_rect>(p0.x(), p1.x(), p0.z(), p1.z(), p1.y(), m)); l->add(make_shared<xz_rect>(p0.x(), p1.x(), p0.z(), p1.z(), p0.y(), m_low));
+    l->add(make_shared<yz_rect>(p0.y(), p1.y(), p0.z(), p1.z(), p1.x(), m)); l->add(make_shared<yz_rect>(p0.y(), p1.y(), p0.z(), p1.z(), p0.x(), m_low));
+    return l;
+}
+
 struct camera {
     rt_camera_desc d;
     camera(point3 lookfrom, point3 lookat, vec3 vup, double vfov, double aspect_ratio, double aperture, double focus_dist) {
@@ -127,8 +151,11 @@ struct camera {
 
 // ---- flattening ------------------------------------------------------------------------------
 struct flat_scene {
-    std::vector<int32_t> prim_type, prim_mat, mat_type, mat_tex, tex_type, tex_a, tex_b;
-    std::vector<double> prim_geom, mat_param, tex_color;
+    std::vector<int32_t> prim_type, prim_mat, prim_xform, mat_type, mat_tex, tex_type, tex_a, tex_b;
+    std::vector<double> prim_geom, mat_param, tex_color, xform;     // xform: [n][4] degrees about +y, offset
+    // instance transform in force while walking: world = R_y(angle) * object + off
+    struct xf { bool any; double angle; double off[3]; };
+    static xf no_xf() { xf x; x.any = false; x.angle = 0; x.off[0] = x.off[1] = x.off[2] = 0; return x; }
     std::vector<int64_t> tex_off;
     std::vector<uint8_t> texels;
     std::map<const void*, int> mat_ids, tex_ids;
@@ -160,8 +187,29 @@ struct flat_scene {
         mat_ids[m.get()] = id;
         return id;
     }
-    void add(const shared_ptr<sceneobject>& o) {
-        if (auto l = dynamic_cast<sceneobject_list*>(o.get())) { for (auto& c : l->objects) add(c); return; }
+    // Wrappers compose into one rotation about y and one offset.  `outer` is the transform
+    // above the wrapper; the wrapper's own motion acts first, so world = outer(wrapper(object)).
+    static xf under(const xf& outer, double angle, const double* t) {
+        const double r = outer.angle * 3.1415926535897932385 / 180.0, c = std::cos(r), s = std::sin(r);
+        xf x = no_xf(); x.any = true; x.angle = outer.angle + angle;
+        x.off[0] = c * t[0] + s * t[2] + outer.off[0];               // cuda/sceneobject.h:98-99
+        x.off[1] = t[1] + outer.off[1];
+        x.off[2] = -s * t[0] + c * t[2] + outer.off[2];
+        return x;
+    }
+    int xform_id(const xf& x) {
+        if (!x.any) return -1;
+        for (size_t i = 0; i < xform.size() / 4; i++)
+            if (xform[4 * i] == x.angle && xform[4 * i + 1] == x.off[0] && xform[4 * i + 2] == x.off[1] && xform[4 * i + 3] == x.off[2]) return (int)i;
+        xform.push_back(x.angle); xform.insert(xform.end(), x.off, x.off + 3);
+        return (int)(xform.size() / 4) - 1;
+    }
+    void add(const shared_ptr<sceneobject>& o) { add(o, no_xf()); }
+    void add(const shared_ptr<sceneobject>& o, const xf& x) {
+        if (auto l = dynamic_cast<sceneobject_list*>(o.get())) { for (auto& c : l->objects) add(c, x); return; }
+        if (auto r = dynamic_cast<rotate_y*>(o.get())) { const double zero[3] = {0, 0, 0}; add(r->ptr, under(x, r->angle, zero)); return; }
+        if (auto t = dynamic_cast<translate*>(o.get())) { add(t->ptr, under(x, 0.0, t->offset.e)); return; }
+        prim_xform.push_back(xform_id(x));
         double g[6] = {0, 0, 0, 0, 0, 0};
         if (auto s = dynamic_cast<sphere*>(o.get())) {
             prim_type.push_back(RT_SPHERE); prim_mat.push_back(mat_id(s->mat_ptr));
@@ -184,6 +232,7 @@ struct flat_scene {
         d.texels = texels.data(); d.texel_bytes = texels.size();
         d.background = background; d.bg_color[0] = (float)bg[0]; d.bg_color[1] = (float)bg[1]; d.bg_color[2] = (float)bg[2];
         d.accel = accel; d.wide_radius = 0;
+        d.n_xforms = (int32_t)(xform.size() / 4); d.xform = xform.data(); d.prim_xform = prim_xform.data();
         return d;
     }
 };

@@ -41,6 +41,7 @@ class _Scene(C.Structure):
         ("tex_a", C.c_void_p), ("tex_b", C.c_void_p), ("tex_off", C.c_void_p),
         ("texels", C.c_void_p),
         ("background", C.c_int32), ("bg_color", C.c_double * 3),
+        ("n_xforms", C.c_int32), ("xform", C.c_void_p), ("prim_xform", C.c_void_p),
     ]
 
 
@@ -76,6 +77,14 @@ class _Packed:
         for name in ("prim_type", "prim_geom", "prim_mat", "mat_type", "mat_param", "mat_tex",
                      "tex_type", "tex_color", "tex_a", "tex_b", "tex_off", "texels"):
             setattr(s, name, k[name].ctypes.data if k[name].size else None)
+        xf = getattr(sc, "xform", None)
+        if xf is not None and np.size(xf):
+            k["xform"] = _arr(xf, np.float64).reshape(-1, 4)
+            k["prim_xform"] = _arr(sc.prim_xform, np.int32)
+            assert k["prim_xform"].shape[0] == n
+            s.n_xforms = k["xform"].shape[0]
+            s.xform = k["xform"].ctypes.data
+            s.prim_xform = k["prim_xform"].ctypes.data
         s.background = int(sc.background)
         s.bg_color = (C.c_double * 3)(*[float(x) for x in sc.bg_color])
         self.struct = s

@@ -24,6 +24,7 @@ uint32_t rto_draw(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t segme
 #define M_TAN tan
 #define M_POW pow
 #define M_SIN sin
+#define M_COS cos
 #define M_ACOS acos
 #define M_ATAN2 atan2
 #include "rt_oracle_impl.h"
@@ -36,6 +37,7 @@ uint32_t rto_draw(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t segme
 #undef M_TAN
 #undef M_POW
 #undef M_SIN
+#undef M_COS
 #undef M_ACOS
 #undef M_ATAN2
 
@@ -48,6 +50,7 @@ uint32_t rto_draw(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t segme
 #define M_TAN tanf
 #define M_POW powf
 #define M_SIN sinf
+#define M_COS cosf
 #define M_ACOS acosf
 #define M_ATAN2 atan2f
 #include "rt_oracle_impl.h"

@@ -54,6 +54,11 @@ typedef struct {
     const uint8_t* texels;      /* RGB8 rows, top row first */
     int32_t background;
     double bg_color[3];
+    /* instance wrappers (cuda/sceneobject.h:31-109 rotate_y, plus a translation):
+     * world = R_y(angle) * object + offset for primitives with prim_xform[i] >= 0 */
+    int32_t n_xforms;
+    const double*  xform;       /* n_xforms x 4: angle in degrees, offset x y z */
+    const int32_t* prim_xform;  /* n_prims, -1 = none; may be NULL */
 } rto_scene;
 
 /* camera record: origin(3) lower_left(3) horizontal(3) vertical(3) u(3) v(3) w(3) lens_radius */

@@ -211,6 +211,31 @@ static int S(rect_hit)(int type, const double* geom, S(v3) o, S(v3) d, R t_min, 
     return 1;
 }
 
+/* cuda/sceneobject.h:80-109 (rotate_y::hit) around a translation: the ray is taken into the
+ * instance's frame, the wrapped object is asked, point and normal come back.  Two deliberate
+ * differences from the text: sine and cosine are taken in R, not always in float (line 50-52);
+ * and the record keeps the side of the surface the wrapped object saw -- line 105 calls
+ * set_face_normal with the object-space ray and the world-space normal, which overwrites
+ * front_face with "true" at angle 0 and with a mixed-frame sign otherwise. */
+static int S(instance_hit)(const rto_scene* sc, int xf, int type, const double* geom, S(v3) o, S(v3) d,
+                           R t_min, R t_max, S(hit)* h) {
+    const double* x = sc->xform + 4 * (size_t)xf;
+    const R pi = (R)3.1415926535897932385;
+    R radians = (R)x[0] * pi / (R)180;
+    R sn = M_SIN(radians), cs = M_COS(radians);
+    S(v3) q = S(sub)(o, S(mk)((R)x[1], (R)x[2], (R)x[3]));
+    S(v3) ro = S(mk)(cs * q.e[0] - sn * q.e[2], q.e[1], sn * q.e[0] + cs * q.e[2]);
+    S(v3) rd = S(mk)(cs * d.e[0] - sn * d.e[2], d.e[1], sn * d.e[0] + cs * d.e[2]);
+    int ok = type == RTO_SPHERE ? S(sphere_hit)(geom, ro, rd, t_min, t_max, h)
+                                : S(rect_hit)(type, geom, ro, rd, t_min, t_max, h);
+    if (!ok) return 0;
+    S(v3) p = h->p, n = h->normal;
+    h->p = S(add)(S(mk)(cs * p.e[0] + sn * p.e[2], p.e[1], -sn * p.e[0] + cs * p.e[2]),
+                  S(mk)((R)x[1], (R)x[2], (R)x[3]));
+    h->normal = S(mk)(cs * n.e[0] + sn * n.e[2], n.e[1], -sn * n.e[0] + cs * n.e[2]);
+    return 1;
+}
+
 /* sceneobject_list.h:26-39: the later object wins an exact tie because the range test is
  * inclusive. */
 static int S(world_hit)(const rto_scene* sc, S(v3) o, S(v3) d, R t_min, R t_max, S(hit)* rec) {
@@ -220,7 +245,9 @@ static int S(world_hit)(const rto_scene* sc, S(v3) o, S(v3) d, R t_min, R t_max,
     for (int i = 0; i < sc->n_prims; i++) {
         const double* geom = sc->prim_geom + 6 * (size_t)i;
         int type = sc->prim_type[i];
-        int ok = type == RTO_SPHERE ? S(sphere_hit)(geom, o, d, t_min, closest, &tmp)
+        int xf = sc->n_xforms > 0 && sc->prim_xform ? sc->prim_xform[i] : -1;
+        int ok = xf >= 0 ? S(instance_hit)(sc, xf, type, geom, o, d, t_min, closest, &tmp)
+               : type == RTO_SPHERE ? S(sphere_hit)(geom, o, d, t_min, closest, &tmp)
                                     : S(rect_hit)(type, geom, o, d, t_min, closest, &tmp);
         if (ok) {
             any = 1;

@@ -36,6 +36,7 @@ class SceneDesc(C.Structure):
         ("tex_b", C.c_void_p), ("tex_off", C.c_void_p), ("texels", C.c_void_p), ("texel_bytes", C.c_uint64),
         ("background", C.c_int32), ("bg_color", C.c_float * 3), ("accel", C.c_int32),
         ("wide_radius", C.c_double),
+        ("n_xforms", C.c_int32), ("xform", C.c_void_p), ("prim_xform", C.c_void_p),
     ]
 
 
@@ -142,6 +143,14 @@ def pack_scene(flat, accel=RT_ACCEL_AUTO, wide_radius=0.0):
     d.bg_color = (C.c_float * 3)(*[float(x) for x in flat.bg_color])
     d.accel = int(accel)
     d.wide_radius = float(wide_radius)
+    xf = getattr(flat, "xform", None)
+    if xf is not None and np.size(xf):
+        k["xform"] = np.ascontiguousarray(xf, np.float64).reshape(-1, 4)
+        k["prim_xform"] = np.ascontiguousarray(flat.prim_xform, np.int32)
+        if k["prim_xform"].shape[0] != d.n_prims:
+            raise ValueError("prim_xform needs one entry per primitive")
+        d.n_xforms = k["xform"].shape[0]
+        d.xform, d.prim_xform = _ptr(k["xform"]), _ptr(k["prim_xform"])
     return d, k
 
 

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -233,8 +234,14 @@ int rt_shard_rows(int32_t height, int32_t tile_rows, int32_t tile_first, int32_t
 
 int rt_upload_scene(rt_context* ctx, const rt_scene_desc* d) {
     if (!ctx) return RT_ERR_INVALID;
-    if (!d || d->struct_size != sizeof(rt_scene_desc))
+    // two layouts are accepted: the whole struct, or the one that ends before the instance transforms
+    const bool has_xf_fields = d && d->struct_size == sizeof(rt_scene_desc);
+    if (!d || (!has_xf_fields && d->struct_size != offsetof(rt_scene_desc, n_xforms)))
         return fail(ctx, RT_ERR_INVALID, "rt_scene_desc: null or struct_size mismatch");
+    const int n_xf = has_xf_fields ? d->n_xforms : 0;
+    const int32_t* prim_xf = has_xf_fields && n_xf > 0 ? d->prim_xform : nullptr;
+    if (n_xf < 0 || (n_xf > 0 && !d->xform)) return fail(ctx, RT_ERR_INVALID, "instance transform array missing");
+    if (n_xf > (1 << 22)) return fail(ctx, RT_ERR_UNSUPPORTED, "more than 2^22 instance transforms");
     if (d->n_prims < 0 || d->n_mats < 0 || d->n_tex < 0) return fail(ctx, RT_ERR_INVALID, "negative count");
     if (d->n_prims > 0 && (!d->prim_type || !d->prim_geom || !d->prim_mat))
         return fail(ctx, RT_ERR_INVALID, "primitive arrays missing");
@@ -300,9 +307,24 @@ int rt_upload_scene(rt_context* ctx, const rt_scene_desc* d) {
         if (m.type == RT_DIELECTRIC && !(m.ir > 0.0f)) return fail(ctx, RT_ERR_INVALID, "dielectric needs ir > 0");
     }
 
+    // instance transforms: sine and cosine in double (cuda/sceneobject.h:50-52 takes them in float)
+    std::vector<rt::DXform> xforms((size_t)n_xf);
+    std::vector<double> xf_sin((size_t)n_xf), xf_cos((size_t)n_xf);
+    for (int i = 0; i < n_xf; i++) {
+        const double* x = d->xform + 4 * (size_t)i;
+        if (!std::isfinite(x[0]) || !finite3(x + 1)) return fail(ctx, RT_ERR_INVALID, "instance transform must be finite");
+        double rad = x[0] * 3.1415926535897932385 / 180.0;
+        xf_sin[i] = std::sin(rad); xf_cos[i] = std::cos(rad);
+        rt::DXform& o = xforms[i];
+        o = rt::DXform{};
+        o.s = xf_sin[i]; o.c = xf_cos[i];
+        o.tx = x[1]; o.ty = x[2]; o.tz = x[3];
+    }
+
     // primitives: ordinary spheres (BVH / scan), wide spheres and rects (always tested)
     std::vector<double> sc_c, sc_r;          // ordinary spheres, input order
-    std::vector<int32_t> sc_obj, sc_mat;
+    std::vector<int32_t> sc_obj, sc_mat, sc_xf;
+    bool any_sphere_xf = false;
     std::vector<rt::DWide> wide;
     std::vector<rt::DRect> rects;
     for (int i = 0; i < d->n_prims; i++) {
@@ -310,15 +332,28 @@ int rt_upload_scene(rt_context* ctx, const rt_scene_desc* d) {
         int mat = d->prim_mat[i];
         if (mat < 0 || mat >= d->n_mats) return fail(ctx, RT_ERR_INVALID, "primitive refers outside the material array");
         int type = d->prim_type[i];
+        int xf = prim_xf ? prim_xf[i] : -1;
+        if (xf >= n_xf) return fail(ctx, RT_ERR_INVALID, "primitive refers outside the instance transform array");
+        if (xf < 0) xf = -1;
         if (type == RT_SPHERE) {
             if (!finite3(g) || !std::isfinite(g[3]) || g[3] == 0.0) return fail(ctx, RT_ERR_INVALID, "sphere needs finite centre and non-zero radius");
+            // a turned and shifted sphere is a sphere about the moved centre; the transform is kept
+            // only to turn its texture coordinates back
+            double c[3] = { g[0], g[1], g[2] };
+            if (xf >= 0) {
+                const double* x = d->xform + 4 * (size_t)xf;
+                c[0] = xf_cos[xf] * g[0] + xf_sin[xf] * g[2] + x[1];
+                c[1] = g[1] + x[2];
+                c[2] = -xf_sin[xf] * g[0] + xf_cos[xf] * g[2] + x[3];
+            }
             if (std::fabs(g[3]) > wide_radius) {
                 rt::DWide w{};
-                w.cx = g[0]; w.cy = g[1]; w.cz = g[2]; w.r = g[3]; w.obj = i; w.mat = mat;
+                w.cx = c[0]; w.cy = c[1]; w.cz = c[2]; w.r = g[3]; w.obj = i; w.mat = mat; w.xform = xf + 1;
                 wide.push_back(w);
             } else {
-                sc_c.insert(sc_c.end(), g, g + 3); sc_r.push_back(g[3]);
-                sc_obj.push_back(i); sc_mat.push_back(mat);
+                sc_c.insert(sc_c.end(), c, c + 3); sc_r.push_back(g[3]);
+                sc_obj.push_back(i); sc_mat.push_back(mat); sc_xf.push_back(xf + 1);
+                any_sphere_xf = any_sphere_xf || xf >= 0;
             }
         } else if (type == RT_XY_RECT || type == RT_XZ_RECT || type == RT_YZ_RECT) {
             for (int a = 0; a < 5; a++) if (!std::isfinite(g[a])) return fail(ctx, RT_ERR_INVALID, "rect needs finite bounds");
@@ -327,7 +362,7 @@ int rt_upload_scene(rt_context* ctx, const rt_scene_desc* d) {
             int ka = type == RT_XY_RECT ? 2 : (type == RT_XZ_RECT ? 1 : 0);
             int aa = type == RT_YZ_RECT ? 1 : 0;
             int ba = type == RT_XY_RECT ? 1 : 2;
-            r.axes = ka | (aa << 2) | (ba << 4);
+            r.axes = ka | (aa << 2) | (ba << 4) | ((xf + 1) << 8);
             r.obj = i; r.mat = mat;
             rects.push_back(r);
         } else {
@@ -349,8 +384,10 @@ int rt_upload_scene(rt_context* ctx, const rt_scene_desc* d) {
     std::vector<float4> sph((size_t)ns_pad, make_float4(1e30f, 1e30f, 1e30f, 0.0f));
     std::vector<double4> sph64((size_t)ns_pad, make_double4(1e30, 1e30, 1e30, 1.0));
     std::vector<int2> info((size_t)ns_pad, make_int2(-1, 0));
+    std::vector<int> sph_xf(any_sphere_xf ? (size_t)ns_pad : 0, 0);
     for (int64_t k = 0; k < ns; k++) {
         int32_t i = order[k];
+        if (any_sphere_xf) sph_xf[k] = sc_xf[i];
         sph[k] = make_float4((float)sc_c[3 * i], (float)sc_c[3 * i + 1], (float)sc_c[3 * i + 2], (float)std::fabs(sc_r[i]));
         sph64[k] = make_double4(sc_c[3 * i], sc_c[3 * i + 1], sc_c[3 * i + 2], sc_r[i]);
         info[k] = make_int2(sc_obj[i], sc_mat[i]);
@@ -367,6 +404,7 @@ int rt_upload_scene(rt_context* ctx, const rt_scene_desc* d) {
     if (d->texel_bytes && d->texels) texels.assign(d->texels, d->texels + d->texel_bytes);
     if ((rc = upload(ctx, sph, &s.sph)) || (rc = upload(ctx, sph64, &s.sph64)) || (rc = upload(ctx, info, &s.sph_info)) ||
         (rc = upload(ctx, nodes4, &s.nodes)) || (rc = upload(ctx, wide, &s.wide)) || (rc = upload(ctx, rects, &s.rects)) ||
+        (rc = upload(ctx, xforms, &s.xforms)) || (rc = upload(ctx, sph_xf, &s.sph_xform)) ||
         (rc = upload(ctx, mats, &s.mats)) || (rc = upload(ctx, texs, &s.texs)) || (rc = upload(ctx, texels, &s.texels))) {
         std::string keep = ctx->error;
         free_scene(ctx);

@@ -14,14 +14,26 @@ namespace rt {
 // Its list position and material: (obj, mat).                                        8 B
 
 struct DWide {            // sphere too large for single precision; always tested, in double
-    double cx, cy, cz, r;
-    int obj, mat, pad0, pad1;
+    double cx, cy, cz, r; // centre already in world space
+    int obj, mat;
+    int xform;            // 0, or 1 + index of the instance transform (only turns the texture coordinates)
+    int pad1;
+};
+
+// Instance transform (cuda/sceneobject.h:31-109 plus a translation):
+// world = R_y * object + t, with R_y = [c 0 s; 0 1 0; -s 0 c].
+// Kept in double: the ray is taken into the instance's frame in double, so that the distance to a
+// rect's plane is a difference of nearby numbers formed before rounding to float.
+struct DXform {
+    double s, c;
+    double tx, ty, tz;
+    double pad;
 };
 
 struct DRect {            // cuda/rect.h: plane axis `ka` at k, in-plane axes (aa, ba)
     float a0, a1, b0, b1;
     float k;
-    int axes;             // ka | aa << 2 | ba << 4
+    int axes;             // ka | aa << 2 | ba << 4 | (1 + instance transform, or 0) << 8
     int obj, mat;
 };
 
@@ -58,6 +70,8 @@ struct DScene {
     int n_wide;
     const DRect* rects;
     int n_rects;
+    const DXform* xforms;
+    const int* sph_xform; // per ordinary sphere (leaf order): 0 or 1 + transform; null when no sphere has one
     const DMaterial* mats;
     const DTexture* texs;
     const uint8_t* texels;

@@ -130,11 +130,35 @@ __device__ __forceinline__ bool sphere_test(float4 s, V3 o, V3 dh, float tn_min,
     return true;
 }
 
-// cuda/rect.h:29-52 (xy), 75-99 (xz), 122-146 (yz); parametric t.  A ray parallel to the plane
-// never hits.
-__device__ __forceinline__ bool rect_test(const DRect& r, V3 o, V3 d, float t_min, float t_max, float& t_out) {
+// cuda/sceneobject.h:84-88: a world-space ray seen from the instance (the translation comes off
+// first), in double and rounded once; `num` is the distance from the origin to the plane
+// coordinate k along axis ka, formed before rounding.  cuda/sceneobject.h:98-102: an
+// object-space direction back in the world.
+struct ObjRay { V3 o, d; float num; };
+__device__ __forceinline__ ObjRay to_object(const DXform& x, V3 o, V3 d, int ka, float k) {
+    double qx = (double)o.x - x.tx, qy = (double)o.y - x.ty, qz = (double)o.z - x.tz;
+    double ox = fma(x.c, qx, -x.s * qz), oz = fma(x.s, qx, x.c * qz);
+    double dx = fma(x.c, (double)d.x, -x.s * (double)d.z), dz = fma(x.s, (double)d.x, x.c * (double)d.z);
+    ObjRay r;
+    r.o = mk((float)ox, (float)qy, (float)oz);
+    r.d = mk((float)dx, d.y, (float)dz);
+    r.num = (float)((double)k - (ka == 0 ? ox : (ka == 1 ? qy : oz)));
+    return r;
+}
+__device__ __forceinline__ V3 to_object_dir(const DXform& x, V3 v) {
+    float c = (float)x.c, s = (float)x.s;
+    return mk(fmaf(c, v.x, -s * v.z), v.y, fmaf(s, v.x, c * v.z));
+}
+__device__ __forceinline__ V3 to_world_dir(const DXform& x, V3 v) {
+    float c = (float)x.c, s = (float)x.s;
+    return mk(fmaf(c, v.x, s * v.z), v.y, fmaf(-s, v.x, c * v.z));
+}
+
+// cuda/rect.h:29-52 (xy), 75-99 (xz), 122-146 (yz); parametric t; num = k - origin along the
+// plane's axis.  A ray parallel to the plane never hits.
+__device__ __forceinline__ bool rect_test(const DRect& r, float num, V3 o, V3 d, float t_min, float t_max, float& t_out) {
     int ka = r.axes & 3, aa = (r.axes >> 2) & 3, ba = (r.axes >> 4) & 3;
-    float t = (r.k - comp(o, ka)) / comp(d, ka);
+    float t = num / comp(d, ka);
     if (!(t >= t_min && t <= t_max)) return false;
     float av = fmaf(t, comp(d, aa), comp(o, aa));
     float bv = fmaf(t, comp(d, ba), comp(o, ba));
@@ -223,9 +247,13 @@ __device__ __forceinline__ RayN normalise(V3 d, float t_min) {
 }
 
 // Always-tested primitives: wide spheres (double) and rects.  They run first and tighten the
-// distance bound the BVH traversal prunes with.
+// distance bound the BVH traversal prunes with.  `from_rect` is the list position of the rect
+// the ray starts on (or -1): a ray that leaves a plane meets that plane again only at t = 0,
+// which the double-precision reference rejects as below t_min, while the float hit point lies
+// up to an ulp of its coordinates off the plane and a grazing ray would find it again.
 template <bool COUNT>
-__device__ __forceinline__ void hit_always(const DScene& sc, V3 o, V3 d, const RayN& rn, float t_min, Cand& best, Counters& cn) {
+__device__ __forceinline__ void hit_always(const DScene& sc, V3 o, V3 d, const RayN& rn, float t_min, int from_rect,
+                                           Cand& best, Counters& cn) {
     for (int i = 0; i < sc.n_wide; i++) {
         const DWide w = sc.wide[i];
         double t;
@@ -240,7 +268,14 @@ __device__ __forceinline__ void hit_always(const DScene& sc, V3 o, V3 d, const R
         const DRect r = sc.rects[i];
         float t;
         if (COUNT) cn.rect++;
-        if (rect_test(r, o, d, t_min, kInf, t)) {
+        if (r.obj == from_rect) continue;
+        ObjRay q;
+        if (r.axes >> 8) {                   // instance: a rotation keeps |d|, so t means the same
+            q = to_object(sc.xforms[(r.axes >> 8) - 1], o, d, r.axes & 3, r.k);
+        } else {
+            q.o = o; q.d = d; q.num = r.k - comp(o, r.axes & 3);
+        }
+        if (rect_test(r, q.num, q.o, q.d, t_min, kInf, t)) {
             float tn = t * rn.len;
             if (better(tn, r.obj, best)) { best.tn = tn; best.td = (double)t; best.kind = 2; best.idx = i; best.obj = r.obj; }
         }
@@ -360,7 +395,7 @@ template <bool COUNT>
 __device__ __forceinline__ Cand closest_hit(const DScene& sc, V3 o, V3 d, float t_min, int* stack, Counters& cn) {
     Cand best = no_hit();
     RayN rn = normalise(d, t_min);
-    hit_always<COUNT>(sc, o, d, rn, t_min, best, cn);
+    hit_always<COUNT>(sc, o, d, rn, t_min, -1, best, cn);
     GeoGlobal geo = {sc.nodes, sc.sph, sc.sph_info};
     if (!sc.use_bvh) hit_list<COUNT>(sc, o, rn, best, cn);
     else if (sc.root != kNoBvh) {
@@ -390,6 +425,12 @@ __device__ __forceinline__ void sphere_uv(V3 on, float& u, float& v) {
     v = theta * (1.0f / pi);
 }
 
+// texture coordinates of a sphere instance come from the normal in its own frame
+__device__ __forceinline__ void sphere_uv_inst(const DScene& sc, int xform, V3 on, float& u, float& v) {
+    if (xform) on = to_object_dir(sc.xforms[xform - 1], on);
+    sphere_uv(on, u, v);
+}
+
 __device__ __forceinline__ void face(Rec& r, V3 d, V3 outward) {
     r.front = dot(d, outward) < 0.0f;
     r.n = r.front ? outward : -outward;
@@ -408,18 +449,34 @@ __device__ __forceinline__ Rec make_record(const DScene& sc, const Cand& c, V3 o
         float t = (float)c.td;
         r.t = t;
         r.p = madd(o, t, d);
-        r.u = (comp(r.p, aa) - q.a0) / (q.a1 - q.a0);
-        r.v = (comp(r.p, ba) - q.b0) / (q.b1 - q.b0);
-        face(r, d, mk(ka == 0 ? 1.0f : 0.0f, ka == 1 ? 1.0f : 0.0f, ka == 2 ? 1.0f : 0.0f));
+        V3 axis = mk(ka == 0 ? 1.0f : 0.0f, ka == 1 ? 1.0f : 0.0f, ka == 2 ? 1.0f : 0.0f);
+        V3 po = r.p;
+        if (q.axes >> 8) {
+            // the instance's own hit record, then point and normal back in the world.  The side
+            // of the surface is the one the instance saw (cuda/sceneobject.h:105 asks again with
+            // the object-space ray against the world-space normal, which mixes the two frames).
+            const DXform x = sc.xforms[(q.axes >> 8) - 1];
+            ObjRay oq = to_object(x, o, d, ka, q.k);
+            po = madd(oq.o, t, oq.d);
+            face(r, oq.d, axis);
+            r.n = to_world_dir(x, r.n);
+        } else {
+            face(r, d, axis);
+        }
+        r.u = (comp(po, aa) - q.a0) / (q.a1 - q.a0);
+        r.v = (comp(po, ba) - q.b0) / (q.b1 - q.b0);
         r.mat = q.mat;
         return r;
     }
     double cx, cy, cz, rad, t;
+    int xform = 0;
     if (c.kind == 1) {
         const DWide w = sc.wide[c.idx];
         cx = w.cx; cy = w.cy; cz = w.cz; rad = w.r; t = c.td;
         r.mat = w.mat;
+        xform = w.xform;
     } else {
+        if (want_uv && sc.sph_xform) xform = sc.sph_xform[c.idx];
         float len = sqrtf(dot(d, d));
         float tf = c.tn / len;
         r.mat = sc.sph_info[c.idx].y;
@@ -429,7 +486,7 @@ __device__ __forceinline__ Rec make_record(const DScene& sc, const Cand& c, V3 o
             r.p = madd(o, tf, d);
             V3 on = (1.0f / s.w) * mk(r.p.x - s.x, r.p.y - s.y, r.p.z - s.z);
             face(r, d, on);
-            if (want_uv) sphere_uv(on, r.u, r.v);
+            if (want_uv) sphere_uv_inst(sc, xform, on, r.u, r.v);
             return r;
         }
         double4 s = sc.sph64[c.idx];
@@ -458,7 +515,7 @@ __device__ __forceinline__ Rec make_record(const DScene& sc, const Cand& c, V3 o
     r.t = (float)t;
     r.p = mk((float)px, (float)py, (float)pz);
     face(r, d, on);
-    if (want_uv) sphere_uv(on, r.u, r.v);
+    if (want_uv) sphere_uv_inst(sc, xform, on, r.u, r.v);
     return r;
 }
 
@@ -645,7 +702,7 @@ __device__ __forceinline__ unsigned long long clk() { return __builtin_amdgcn_s_
 // L collects the path's radiance: emitted light along the way and the background at the end.
 template <bool COUNT>
 __device__ __forceinline__ bool shade(const DScene& sc, const DRender& rp, const Cand& c, const Key& key, int depth,
-                                      bool refine, const RayN& rn, V3& o, V3& d, V3& T, V3& L, Counters& cn) {
+                                      bool refine, const RayN& rn, V3& o, V3& d, V3& T, V3& L, int& from_rect, Counters& cn) {
     if (c.kind < 0) {
         L = L + T * background(sc, rn.dh);
         return true;
@@ -664,6 +721,7 @@ __device__ __forceinline__ bool shade(const DScene& sc, const DRender& rp, const
     T = T * att;
     o = r.p;
     d = sd;
+    from_rect = c.kind == 2 ? c.obj : -1;
     return !cont || depth >= rp.max_depth;             // main.cc:13-14: the limit ends in black
 }
 
@@ -768,6 +826,7 @@ __global__ __launch_bounds__(kBlock, 5) void render_kernel(DScene sc, DCamera ca
     unsigned long long next = 0ull;                    // wave-uniform: first unit not handed out yet
     bool has = false;                                  // this lane is on a path
     int q = 0, depth = 0;                              // pixel of the tile, rays traced on the path
+    int from_rect = -1;                                // list position of the rect the ray starts on
     V3 o = mk(0, 0, 0), d = mk(0, 0, 1), T = mk(1, 1, 1), L = mk(0, 0, 0);
     // closest-hit query in progress: candidate so far and traversal position.  cur == kTravDone
     // on a lane with a path means "ray not started yet".
@@ -789,6 +848,7 @@ __global__ __launch_bounds__(kBlock, 5) void render_kernel(DScene sc, DCamera ca
                     T = mk(1.0f, 1.0f, 1.0f);
                     L = mk(0.0f, 0.0f, 0.0f);
                     depth = 0;
+                    from_rect = -1;
                     nsamples++;
                     has = true;
                 }
@@ -810,7 +870,7 @@ __global__ __launch_bounds__(kBlock, 5) void render_kernel(DScene sc, DCamera ca
             int& spq = *(SLICED ? &sp : &sp_trip);
             if (curq == kTravDone) {                   // a new ray: always-tested primitives first
                 cq = no_hit();
-                hit_always<COUNT>(sc, o, d, rn, rp.t_min, cq, cn);
+                hit_always<COUNT>(sc, o, d, rn, rp.t_min, from_rect, cq, cn);
                 nrays++;
                 depth++;
                 if (!sc.use_bvh) hit_list<COUNT>(sc, o, rn, cq, cn);
@@ -820,7 +880,7 @@ __global__ __launch_bounds__(kBlock, 5) void render_kernel(DScene sc, DCamera ca
             if (curq != kTravDone) hit_bvh<COUNT, SLICED>(geo, o, rn, stack, rp.slice, curq, spq, cq, cn);
             if (PROF) { unsigned long long t = clk(); ph[2] += t - tq; tq = t; }
             if (curq == kTravDone) {                   // query finished (else: resumed next trip)
-                if (shade<COUNT>(sc, rp, cq, key, depth, refine, rn, o, d, T, L, cn)) {
+                if (shade<COUNT>(sc, rp, cq, key, depth, refine, rn, o, d, T, L, from_rect, cn)) {
                     atomicAdd(&accum[q * 3 + 0], to_fixed(L.x));
                     atomicAdd(&accum[q * 3 + 1], to_fixed(L.y));
                     atomicAdd(&accum[q * 3 + 2], to_fixed(L.z));

@@ -161,6 +161,33 @@ class sceneobject_list(sceneobject):
         self.objects.append(obj)
 
 
+class rotate_y(sceneobject):
+    """cuda/sceneobject.h:31-47: `p` turned by `angle` degrees about the world's +y axis."""
+
+    def __init__(self, p, angle):
+        self.ptr, self.angle = p, float(angle)
+
+
+class translate(sceneobject):
+    """`p` moved by `displacement`.  The reference's tree only has the rotation wrapper; the
+    translation is the companion every use of rotate_y needs (an object turns about the world's
+    y axis, not its own)."""
+
+    def __init__(self, p, displacement):
+        self.ptr, self.offset = p, _v(displacement)
+
+
+def box(p0, p1, mat, mat_low=None):
+    """The six rects of an axis-aligned box in the order of cuda/main.cu:130-137: per axis pair
+    the face at p1 first (material `mat`), then the face at p0 (`mat_low`, default `mat`)."""
+    p0, p1 = _v(p0), _v(p1)
+    lo = mat if mat_low is None else mat_low
+    return sceneobject_list([
+        xy_rect(p0[0], p1[0], p0[1], p1[1], p1[2], mat), xy_rect(p0[0], p1[0], p0[1], p1[1], p0[2], lo),
+        xz_rect(p0[0], p1[0], p0[2], p1[2], p1[1], mat), xz_rect(p0[0], p1[0], p0[2], p1[2], p0[1], lo),
+        yz_rect(p0[1], p1[1], p0[2], p1[2], p1[0], mat), yz_rect(p0[1], p1[1], p0[2], p1[2], p0[0], lo)])
+
+
 class bvh_node(sceneobject):
     """Grouping marker kept for source compatibility (cuda/bvh.h:18).  The GPU path builds one
     BVH over the whole flattened scene, so a bvh_node only contributes its members."""
@@ -278,25 +305,58 @@ class FlatScene:
     background: int = RT_BG_SKY
     bg_color: tuple = (0.0, 0.0, 0.0)
     meta: dict = field(default_factory=dict)
+    xform: np.ndarray = field(default_factory=lambda: np.zeros((0, 4), np.float64))   # [x,4] degrees about +y, offset
+    prim_xform: np.ndarray = None                                                     # [n] index into xform or -1
 
     @property
     def n_prims(self):
         return int(self.prim_type.shape[0])
 
 
-def _walk(obj, out):
+def _walk(obj, out, xf=None):
+    """Collects (primitive, transform) leaves.  A transform is (angle, offset) meaning
+    world = R_y(angle) * object + offset; wrappers compose into that one form:
+    translate adds to the offset, rotate_y adds to the angle and turns the offset."""
     if isinstance(obj, (sceneobject_list, bvh_node)):
         for o in obj.objects:
-            _walk(o, out)
+            _walk(o, out, xf)
+    elif isinstance(obj, (translate, rotate_y)):
+        # the wrapper acts on what its child produces, so the child's own transform is the
+        # inner one: walk down with a list of wrappers, outermost first
+        _walk(obj.ptr, out, (xf or ()) + (obj,))
     elif isinstance(obj, (sphere, _rect)):
-        out.append(obj)
+        out.append((obj, _compose(xf)))
     else:
         raise TypeError(f"not a scene object: {type(obj).__name__}")
 
 
+def _compose(wrappers):
+    if not wrappers:
+        return None
+    angle, off = 0.0, np.zeros(3)
+    for w in reversed(wrappers):                      # innermost wrapper acts first
+        if isinstance(w, translate):
+            off = off + w.offset
+        else:
+            r = np.deg2rad(w.angle)
+            c, s_ = np.cos(r), np.sin(r)
+            off = np.array([c * off[0] + s_ * off[2], off[1], -s_ * off[0] + c * off[2]])   # cuda/sceneobject.h:98-99
+            angle += w.angle
+    return (angle, *off)
+
+
 def flatten(world, background=RT_BG_SKY, bg_color=(0.0, 0.0, 0.0)) -> FlatScene:
-    prims = []
-    _walk(world, prims)
+    leaves = []
+    _walk(world, leaves)
+    prims = [o for o, _ in leaves]
+    xforms, xform_ids = [], {}
+    pxf = np.full(len(leaves), -1, np.int32)
+    for i, (_, xf) in enumerate(leaves):
+        if xf is not None:
+            if xf not in xform_ids:
+                xform_ids[xf] = len(xforms)
+                xforms.append(xf)
+            pxf[i] = xform_ids[xf]
     mats, mat_ids = [], {}
     texs, tex_ids = [], {}
     blobs, blob_bytes = [], 0
@@ -369,7 +429,8 @@ def flatten(world, background=RT_BG_SKY, bg_color=(0.0, 0.0, 0.0)) -> FlatScene:
         tex_b=np.array([x[3] for x in texs], np.int32).reshape(t),
         tex_off=np.array([x[4] for x in texs], np.int64).reshape(t),
         texels=(np.concatenate(blobs) if blobs else np.zeros(0, np.uint8)),
-        background=int(background), bg_color=_v(bg_color))
+        background=int(background), bg_color=_v(bg_color),
+        xform=np.array(xforms, np.float64).reshape(len(xforms), 4), prim_xform=pxf)
 
 
 # ---- scenes of the benchmark configurations ----------------------------------------------------------
@@ -426,6 +487,29 @@ def cornell_scene():
     w.add(xz_rect(0, 555, 0, 555, 0, white))
     w.add(xz_rect(0, 555, 0, 555, 555, white))
     w.add(xy_rect(0, 555, 0, 555, 555, white))
+    return w
+
+
+def cornell_boxes_scene():
+    """The same room holding two turned boxes instead of the spheres: the arrangement
+    cuda/sceneobject.h's rotate_y exists for (a box of six rects, cuda/main.cu:126-137, turned
+    about y and set in place).  Sizes and angles: 165 x 330 x 165 at +15 degrees moved to
+    (265, 0, 295); 165 x 165 x 165 at -18 degrees moved to (130, 0, 65).  A glass sphere rides on
+    the short box so that a refracting object is seen through an instance."""
+    white = lambertian((.73, .73, .73))
+    red = lambertian((.65, .05, .05))
+    green = lambertian((.12, .45, .15))
+    light = diffuse_light((7, 7, 7))
+    w = sceneobject_list()
+    w.add(yz_rect(0, 555, 0, 555, 555, green))
+    w.add(yz_rect(0, 555, 0, 555, 0, red))
+    w.add(xz_rect(75, 270, 76, 280, 554, light))
+    w.add(xz_rect(0, 555, 0, 555, 0, white))
+    w.add(xz_rect(0, 555, 0, 555, 555, white))
+    w.add(xy_rect(0, 555, 0, 555, 555, white))
+    w.add(translate(rotate_y(box((0, 0, 0), (165, 330, 165), white), 15), (265, 0, 295)))
+    w.add(translate(rotate_y(box((0, 0, 0), (165, 165, 165), white), -18), (130, 0, 65)))
+    w.add(translate(rotate_y(sphere((82.5, 215, 82.5), 50.0, dielectric(1.5)), -18), (130, 0, 65)))
     return w
 
 

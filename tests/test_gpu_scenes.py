@@ -46,7 +46,7 @@ def _rmse(img, sums, spp):
 
 # ---- Cornell box: rects + emitter + glass/metal spheres, black background ---------------------
 
-def _cornell(api, S, oracle):
+def _cornell(api, S, oracle=None):
     flat = S.flatten(S.cornell_scene(), background=S.RT_BG_SOLID, bg_color=(0, 0, 0))
     cam = S.cornell_camera(1.5).desc()
     ctx = api.Context(0)
@@ -89,6 +89,84 @@ def test_cornell_image_matches_restatement(api, S, oracle):
     assert abs(st["rays"] - rays) / rays < 0.005
     assert img[..., :3].max() > 0          # the light is seen
     ctx.close()
+
+
+# ---- instances: boxes of six rects turned about y and moved (cuda/sceneobject.h:31-109) ---------------
+
+def _cornell_boxes(api, S):
+    flat = S.flatten(S.cornell_boxes_scene(), background=S.RT_BG_SOLID, bg_color=(0, 0, 0))
+    cam = S.cornell_camera(1.5).desc()
+    ctx = api.Context(0)
+    ctx.upload_scene(flat)
+    ctx.set_camera(**cam)
+    return flat, cam, ctx
+
+
+def test_instances_closest_hits(api, S, oracle):
+    flat, cam, ctx = _cornell_boxes(api, S)
+    rng = np.random.default_rng(15)
+    cd = oracle.camera(**cam)
+    rays = [oracle.get_ray(cd, rng.random(), rng.random(), 3, k, 0)[0] for k in range(3000)]
+    for k in range(3000):
+        o = rng.uniform(5, 550, 3)
+        rays.append(np.concatenate([o, _unit(rng.normal(size=3)) * rng.uniform(0.2, 2)]))
+    # from inside the glass sphere that rides on the turned short box
+    c, s = np.cos(np.deg2rad(-18.0)), np.sin(np.deg2rad(-18.0))
+    glass = np.array([c * 82.5 + s * 82.5 + 130, 215.0, -s * 82.5 + c * 82.5 + 65])
+    for k in range(500):
+        rays.append(np.concatenate([glass + rng.uniform(-20, 20, 3), _unit(rng.normal(size=3))]))
+    rays = _f32(np.array(rays))
+    want = oracle.trace(flat, rays)
+    hits = ctx.trace_primary(rays)
+    # a ray that runs into a box edge-on may take either face in float
+    _check_hits(hits, want, uv_abs=5e-6, allow_id_mismatch=2)
+    assert set(range(6, 19)) <= set(np.unique(want["id"]))            # all twelve faces and the sphere
+    inside = want["id"][-500:] == 18
+    assert inside.sum() > 400 and (hits["front_face"][-500:][inside] == 0).all()
+    ctx.close()
+
+
+def test_instances_image_matches_restatement(api, S, oracle):
+    flat, cam, ctx = _cornell_boxes(api, S)
+    W, H, spp = 96, 64, 32
+    img = ctx.render_host(api.Context.params(W, H, spp, 50, 23))
+    st = ctx.stats()
+    sums, rays = oracle.render(flat, oracle.camera(**cam), W, H, spp, 50, 23, threads=8)
+    assert _rmse(img, sums, spp) <= 0.03, _rmse(img, sums, spp)
+    assert abs(img[..., :3].mean() / spp - sums.mean() / spp) < 5e-3
+    assert abs(st["rays"] - rays) / rays < 0.005
+    ctx.close()
+
+
+def test_textured_sphere_instance_turns_its_texture(api, S, oracle):
+    """A globe turned about y: the hit is the moved sphere's, the texture coordinates turn with
+    it (the frames of a spinning planet differ only in this angle)."""
+    tex = S.image_texture(64, 32, S.procedural_image(64, 32))
+    rays = None
+    for angle in (0.0, 75.0, -200.0):
+        w = S.sceneobject_list()
+        w.add(S.sphere((0, -1000, 0), 1000, S.lambertian((0.5, 0.5, 0.5))))
+        w.add(S.translate(S.rotate_y(S.sphere((0, 0, 0), 1.0, S.lambertian(tex)), angle), (0.5, 1, -0.25)))
+        w.add(S.translate(S.rotate_y(S.sphere((0, 0, 0), 100.0, S.lambertian_bg(tex)), angle), (300, 100, 0)))
+        flat = S.flatten(w)
+        cam = dict(lookfrom=(0, 2, 7), lookat=(0.5, 1, 0), vup=(0, 1, 0), vfov=30.0, aspect=1.5, aperture=0.0, focus_dist=7.0)
+        ctx = api.Context(0)
+        ctx.upload_scene(flat)
+        ctx.set_camera(**cam)
+        if rays is None:
+            rng = np.random.default_rng(9)
+            cd = oracle.camera(**cam)
+            rays = [oracle.get_ray(cd, rng.random(), rng.random(), 4, k, 0)[0] for k in range(2000)]
+            rays += [np.concatenate([[0, 2, 7], _unit(np.array([300, 100, 0]) - [0, 2, 7] + 60 * rng.normal(size=3))]) for _ in range(1000)]
+            rays = _f32(np.array(rays))
+        want = oracle.trace(flat, rays)
+        hits = ctx.trace_primary(rays)
+        _check_hits(hits, want, uv_abs=2e-5)
+        assert (want["id"] == 1).sum() > 200 and (want["id"] == 2).sum() > 300
+        img = ctx.render_host(api.Context.params(48, 32, 16, 10, 3))
+        sums, _ = oracle.render(flat, oracle.camera(**cam), 48, 32, 16, 10, 3, threads=8)
+        assert _rmse(img, sums, 16) <= 0.02
+        ctx.close()
 
 
 # ---- textures: checker (nested) and image, on spheres and rects -------------------------------------
