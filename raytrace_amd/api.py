@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "librt_amd.so")
 RT_OK = 0
 RT_ERR_INVALID, RT_ERR_NO_DEVICE, RT_ERR_HIP, RT_ERR_NO_SCENE, RT_ERR_NO_CAMERA, RT_ERR_UNSUPPORTED = \
     -1, -2, -3, -4, -5, -6
-RT_ACCEL_AUTO, RT_ACCEL_LIST, RT_ACCEL_BVH = 0, 1, 2
+RT_ACCEL_AUTO, RT_ACCEL_LIST, RT_ACCEL_BVH, RT_ACCEL_BVH_DEVICE = 0, 1, 2, 3
 RT_FLAG_MEAN, RT_FLAG_NO_REFINE, RT_FLAG_COUNTERS, RT_FLAG_PHASE_CLOCKS, RT_FLAG_NO_LDS_SCENE = 1, 2, 4, 8, 32
 
 EXPORTS = ["rt_create", "rt_destroy", "rt_set_stream", "rt_upload_scene", "rt_set_camera",
@@ -69,7 +69,7 @@ class Stats(C.Structure):
                 ("wide_tests", C.c_uint64), ("shades", C.c_uint64), ("phase_clocks", C.c_uint64 * 5),
                 ("kernel_ms", C.c_float),
                 ("lanes_per_pixel", C.c_int32), ("accel", C.c_int32), ("bvh_nodes", C.c_int32),
-                ("bvh_depth", C.c_int32)]
+                ("bvh_depth", C.c_int32), ("build_ms", C.c_float)]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_}

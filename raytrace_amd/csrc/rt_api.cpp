@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstddef>
 #include <cstdio>
@@ -14,6 +15,7 @@
 
 #include "rt_bvh.h"
 #include "rt_device.h"
+#include "rt_lbvh.h"
 
 struct rt_context {
     int device = 0;
@@ -27,6 +29,7 @@ struct rt_context {
     std::vector<void*> scene_allocs;
     int accel_used = RT_ACCEL_LIST;
     int bvh_nodes = 0, bvh_depth = 0;
+    float build_ms = 0.0f;
 
     // per-render state
     unsigned long long* counters = nullptr;   // device, rt::kNumCounters
@@ -249,7 +252,7 @@ int rt_upload_scene(rt_context* ctx, const rt_scene_desc* d) {
         return fail(ctx, RT_ERR_INVALID, "material arrays missing");
     if (d->n_tex > 0 && (!d->tex_type || !d->tex_color || !d->tex_a || !d->tex_b || !d->tex_off))
         return fail(ctx, RT_ERR_INVALID, "texture arrays missing");
-    if (d->accel < RT_ACCEL_AUTO || d->accel > RT_ACCEL_BVH) return fail(ctx, RT_ERR_INVALID, "unknown accel");
+    if (d->accel < RT_ACCEL_AUTO || d->accel > RT_ACCEL_BVH_DEVICE) return fail(ctx, RT_ERR_INVALID, "unknown accel");
     if (d->background != RT_BG_SKY && d->background != RT_BG_SOLID) return fail(ctx, RT_ERR_INVALID, "unknown background");
     if (d->n_prims > (1 << 28)) return fail(ctx, RT_ERR_UNSUPPORTED, "more than 2^28 primitives");
     const double wide_radius = d->wide_radius > 0 ? d->wide_radius : 64.0;
@@ -371,15 +374,21 @@ int rt_upload_scene(rt_context* ctx, const rt_scene_desc* d) {
     }
     const int64_t ns = (int64_t)sc_r.size();
 
-    bool use_bvh = d->accel == RT_ACCEL_BVH || (d->accel == RT_ACCEL_AUTO && ns > 32);
+    bool use_bvh = d->accel == RT_ACCEL_BVH || d->accel == RT_ACCEL_BVH_DEVICE || (d->accel == RT_ACCEL_AUTO && ns > 32);
+    // the GPU builder needs an inner root; a handful of spheres goes through the host builder
+    // RT_ACCEL_AUTO: from 65536 spheres on the host build (0.5 s per million) costs more than the
+    // few percent of traversal time its tree saves on a frame
+    const bool device_build = (d->accel == RT_ACCEL_BVH_DEVICE && ns > 4) || (d->accel == RT_ACCEL_AUTO && ns >= 65536);
+    const auto t_build = std::chrono::steady_clock::now();
     rt::BvhResult bvh;
     std::vector<int32_t> order((size_t)ns);
     for (int64_t i = 0; i < ns; i++) order[i] = (int32_t)i;
-    if (use_bvh) {
+    if (use_bvh && !device_build) {
         bvh = rt::build_bvh(sc_c.data(), sc_r.data(), ns, rt::kMaxStack - 4);
         if (bvh.depth > rt::kMaxStack - 2) return fail(ctx, RT_ERR_UNSUPPORTED, "BVH deeper than the traversal stack");
         order = bvh.order;
     }
+    // sphere arrays in leaf order (input order when the GPU builder will permute them)
     const int64_t ns_pad = (ns + 3) / 4 * 4;
     std::vector<float4> sph((size_t)ns_pad, make_float4(1e30f, 1e30f, 1e30f, 0.0f));
     std::vector<double4> sph64((size_t)ns_pad, make_double4(1e30, 1e30, 1e30, 1.0));
@@ -411,11 +420,40 @@ int rt_upload_scene(rt_context* ctx, const rt_scene_desc* d) {
         ctx->error = keep;
         return rc;
     }
+    int n_nodes = (int)(bvh.nodes.size() / 16), root = use_bvh ? bvh.root : rt::kNoBvh, depth = bvh.depth;
+    if (device_build) {
+        // build over the uploaded (input order) spheres, then permute the arrays into leaf
+        // order; the second set of arrays starts as a copy so that it carries the padding
+        rt::LbvhResult lb;
+        hipError_t e = rt::build_lbvh(s.sph64, (int)ns, ctx->stream, &lb);
+        const float4* sph2 = nullptr; const double4* sph642 = nullptr; const int2* info2 = nullptr; const int* xf2 = nullptr;
+        if (e == hipSuccess) {
+            ctx->scene_allocs.push_back(lb.nodes);
+            if (lb.depth > rt::kMaxStack - 2) e = hipErrorInvalidValue;
+        }
+        if (e == hipSuccess && ((rc = upload(ctx, sph, &sph2)) || (rc = upload(ctx, sph64, &sph642)) ||
+                                (rc = upload(ctx, info, &info2)) || (rc = upload(ctx, sph_xf, &xf2)))) e = hipErrorOutOfMemory;
+        if (e == hipSuccess)
+            e = rt::gather_spheres(lb.order, (int)ns, s.sph, s.sph64, s.sph_info, s.sph_xform, const_cast<float4*>(sph2),
+                                   const_cast<double4*>(sph642), const_cast<int2*>(info2), const_cast<int*>(xf2), ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (lb.order) (void)hipFree(lb.order);
+        if (e != hipSuccess) {
+            free_scene(ctx);
+            return fail(ctx, lb.depth > rt::kMaxStack - 2 ? RT_ERR_UNSUPPORTED : RT_ERR_HIP,
+                        lb.depth > rt::kMaxStack - 2 ? std::string("BVH deeper than the traversal stack")
+                                                     : std::string("GPU BVH build: ") + hipGetErrorString(e));
+        }
+        s.sph = sph2; s.sph64 = sph642; s.sph_info = info2; s.sph_xform = xf2;   // the input-order copies stay in scene_allocs until the next upload
+        s.nodes = lb.nodes;
+        n_nodes = lb.n_nodes; root = lb.root; depth = lb.depth;
+    }
+    ctx->build_ms = use_bvh ? std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_build).count() : 0.0f;
     s.n_sph = (int)ns;
     s.n_sph_padded = (int)ns_pad;
-    s.n_nodes = (int)(bvh.nodes.size() / 16);
-    s.root = use_bvh ? bvh.root : rt::kNoBvh;
-    s.bvh_depth = bvh.depth;
+    s.n_nodes = n_nodes;
+    s.root = root;
+    s.bvh_depth = depth;
     s.use_bvh = use_bvh ? 1 : 0;
     s.n_wide = (int)wide.size();
     s.n_rects = (int)rects.size();
@@ -423,8 +461,8 @@ int rt_upload_scene(rt_context* ctx, const rt_scene_desc* d) {
     for (int a = 0; a < 3; a++) s.bg[a] = d->bg_color[a];
     ctx->scene = s;
     ctx->accel_used = use_bvh ? RT_ACCEL_BVH : RT_ACCEL_LIST;
-    ctx->bvh_nodes = (int)(bvh.nodes.size() / 16);
-    ctx->bvh_depth = bvh.depth;
+    ctx->bvh_nodes = n_nodes;
+    ctx->bvh_depth = depth;
     ctx->has_scene = true;
     return RT_OK;
 }
@@ -520,6 +558,7 @@ int rt_get_stats(rt_context* ctx, rt_stats* out) {
     out->accel = ctx->accel_used;
     out->bvh_nodes = ctx->bvh_nodes;
     out->bvh_depth = ctx->bvh_depth;
+    out->build_ms = ctx->build_ms;
     return RT_OK;
 }
 

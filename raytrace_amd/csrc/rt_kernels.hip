@@ -182,14 +182,22 @@ __device__ __forceinline__ bool box_test(float bx0, float by0, float bz0, float 
     return tnear <= fmaf(tfar, 1.0000005f, slack);
 }
 
-// Per-ray constants of the slab test.  A zero direction component gives an infinite reciprocal;
-// its products are +-inf or NaN, which min/max order away from the other axes' planes.
+// Per-ray constants of the slab test.  A direction component of zero (or too small for a finite
+// reciprocal) takes +-1e30 as its reciprocal: the two plane distances of that axis then come out
+// as huge numbers of opposite sign when the origin lies between the planes and of equal sign when
+// it does not, which is the answer for a ray parallel to the slab.  (With an infinite reciprocal
+// b * inf - o * inf is NaN whenever b and o have the same sign.)
 struct SlabRay { V3 idir, oid; float slack; };
 __device__ __forceinline__ SlabRay slab_ray(V3 o, V3 dh) {
     SlabRay r;
-    r.idir = mk(__builtin_amdgcn_rcpf(dh.x), __builtin_amdgcn_rcpf(dh.y), __builtin_amdgcn_rcpf(dh.z));
+    const float lim = 1.0e30f;
+    r.idir = mk(fminf(fmaxf(__builtin_amdgcn_rcpf(dh.x), -lim), lim), fminf(fmaxf(__builtin_amdgcn_rcpf(dh.y), -lim), lim),
+                fminf(fmaxf(__builtin_amdgcn_rcpf(dh.z), -lim), lim));
     r.oid = mk(-o.x * r.idir.x, -o.y * r.idir.y, -o.z * r.idir.z);
-    float big = fmaxf(fmaxf(fabsf(r.oid.x), fabsf(r.oid.y)), fabsf(r.oid.z));
+    // rounding error bound of the fused form, from the axes the ray actually moves along
+    float bx = fabsf(r.idir.x) < lim ? fabsf(r.oid.x) : 0.0f, by = fabsf(r.idir.y) < lim ? fabsf(r.oid.y) : 0.0f,
+          bz = fabsf(r.idir.z) < lim ? fabsf(r.oid.z) : 0.0f;
+    float big = fmaxf(fmaxf(bx, by), bz);
     r.slack = isfinite(big) ? 4.0e-7f * big : 0.0f;
     return r;
 }

@@ -288,6 +288,17 @@ def test_edge_cases(api, S, oracle):
         w.add(S.sphere((4, 0, 0), 1, m))
         ctx.upload_scene(S.flatten(w), accel=accel)
         assert ctx.trace_primary(np.array([[0, 0, 5, 0, 0, -1]], np.float32))["id"][0] == 1   # sphere.h:35 inclusive
+    # rays along an axis (a direction component is exactly zero) through a tree with inner nodes
+    w = S.sceneobject_list([S.sphere((2.5 * k, 1.0 * (k % 2), 0), 1.0, m) for k in range(12)])
+    flat = S.flatten(w)
+    rays = np.array([[2.5 * k, 1.0 * (k % 2), 5, 0, 0, -1] for k in range(12)] +
+                    [[-5, 0, 0, 1, 0, 0], [30, 1, 0, -1, 0, 0], [5, 9, 0, 0, -1, 0], [1.25, 0.5, 5, 0, 0, -1]], np.float32)
+    want = oracle.trace(flat, rays.astype(np.float64))
+    for accel in (api.RT_ACCEL_BVH, api.RT_ACCEL_BVH_DEVICE, api.RT_ACCEL_LIST):
+        ctx.upload_scene(flat, accel=accel)
+        h = ctx.trace_primary(rays)
+        assert list(h["id"]) == list(want["id"]) == list(range(12)) + [0, 11, 2, -1]
+        np.testing.assert_allclose(h["t"], want["t"], rtol=1e-5)
     # ray parallel to a rect's plane and ray hitting exactly its edge
     w = S.sceneobject_list()
     w.add(S.xz_rect(-1, 1, -1, 1, 0.0, S.lambertian((0.5, 0.5, 0.5))))
