@@ -7,6 +7,7 @@
  *   reference call site                                   entry point here
  *   ---------------------------------------------------   -------------------------
  *   create_world<<<1,1>>>        cuda/main.cu:39-189,520   rt_upload_scene
+ *   load_texture: stbi_load      cuda/main.cu:393          rt_load_jpeg_file / rt_decode_jpeg
  *   load_texture (H2D part)      cuda/main.cu:385-436      rt_upload_scene (texels)
  *   rotate_y wrappers            cuda/sceneobject.h:31-109 rt_upload_scene (xform, prim_xform)
  *   camera ctor / update_scene   camera.h:19-38,
@@ -178,6 +179,17 @@ int rt_get_stats(rt_context* ctx, rt_stats* out);
 
 const char* rt_last_error(rt_context* ctx);
 const char* rt_version(void);
+
+/* Texture files (host side, no context): what stbi_load(filename, &w, &h, &n, 3) does for
+ * load_texture (cuda/main.cu:393) -- a JPEG file (baseline or progressive, 8 bit, any 1x/2x/4x
+ * chroma subsampling, restart intervals, grey / YCbCr / RGB / CMYK) decoded to RGB8 rows, top row
+ * first, ready to be an RT_TEX_IMAGE entry.  *rgb8 is allocated by the library: release it with
+ * rt_free_image.  Errors: RT_ERR_INVALID (unreadable or corrupt), RT_ERR_UNSUPPORTED (12-bit,
+ * arithmetic-coded, lossless); text from rt_image_last_error (per thread). */
+int rt_decode_jpeg(const uint8_t* bytes, uint64_t n_bytes, int32_t* width, int32_t* height, uint8_t** rgb8);
+int rt_load_jpeg_file(const char* path, int32_t* width, int32_t* height, uint8_t** rgb8);
+void rt_free_image(uint8_t* rgb8);
+const char* rt_image_last_error(void);
 
 #ifdef __cplusplus
 }

@@ -12,6 +12,7 @@
 //   lambertian / metal / dielectric               material.h:19,40,56
 //   lambertian_bg / diffuse_light                 cuda/material.h:37-38,107-109
 //   rgb_color / checker_texture / image_texture   cuda/texture.h:22,39-41,61
+//   load_texture(filename)                        cuda/main.cu:385-436
 //   camera(lookfrom, lookat, vup, vfov, aspect, aperture, focus_dist)   camera.h:19-20
 //
 // Objects only record what they were built from; `flat_scene` turns a sceneobject_list into the
@@ -64,6 +65,18 @@ struct image_texture : custom_texture {
     std::vector<uint8_t> texels;
     image_texture(uint32_t w, uint32_t h, const uint8_t* rgb8) : texture_width(w), texture_height(h), texels(rgb8, rgb8 + (size_t)w * h * 3) {}
 };
+
+// load_texture of cuda/main.cu:385-436: a JPEG file as an image texture (decoded by the library
+// to the texels the reference's stb_image produces).
+inline shared_ptr<image_texture> load_texture(const char* filename) {
+    int32_t w = 0, h = 0;
+    uint8_t* rgb = nullptr;
+    if (rt_load_jpeg_file(filename, &w, &h, &rgb) != RT_OK)
+        throw std::runtime_error(std::string("load_texture: ") + rt_image_last_error());
+    auto t = make_shared<image_texture>((uint32_t)w, (uint32_t)h, rgb);
+    rt_free_image(rgb);
+    return t;
+}
 
 // ---- materials --------------------------------------------------------------------------
 struct material {

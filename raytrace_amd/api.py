@@ -18,7 +18,8 @@ RT_FLAG_MEAN, RT_FLAG_NO_REFINE, RT_FLAG_COUNTERS, RT_FLAG_PHASE_CLOCKS, RT_FLAG
 
 EXPORTS = ["rt_create", "rt_destroy", "rt_set_stream", "rt_upload_scene", "rt_set_camera",
            "rt_shard_rows", "rt_render", "rt_render_host", "rt_trace_primary", "rt_quantize",
-           "rt_get_stats", "rt_last_error", "rt_version"]
+           "rt_get_stats", "rt_last_error", "rt_version",
+           "rt_decode_jpeg", "rt_load_jpeg_file", "rt_free_image", "rt_image_last_error"]
 
 
 class RtError(RuntimeError):
@@ -109,8 +110,34 @@ def lib():
         L.rt_last_error.argtypes = [C.c_void_p]
         L.rt_last_error.restype = C.c_char_p
         L.rt_version.restype = C.c_char_p
+        L.rt_decode_jpeg.argtypes = [C.c_char_p, C.c_uint64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_void_p)]
+        L.rt_load_jpeg_file.argtypes = [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_void_p)]
+        L.rt_free_image.argtypes = [C.c_void_p]
+        L.rt_free_image.restype = None
+        L.rt_image_last_error.restype = C.c_char_p
         _lib = L
     return _lib
+
+
+def _take_image(rc, w, h, out):
+    if rc != RT_OK:
+        raise RtError(rc, lib().rt_image_last_error().decode())
+    try:
+        return np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint8)), (h.value, w.value, 3)).copy()
+    finally:
+        lib().rt_free_image(out)
+
+
+def decode_jpeg(data: bytes) -> np.ndarray:
+    """JPEG file image in memory -> uint8 [height, width, 3], top row first (rt_decode_jpeg)."""
+    w, h, out = C.c_int32(), C.c_int32(), C.c_void_p()
+    data = bytes(data)
+    return _take_image(lib().rt_decode_jpeg(data, len(data), C.byref(w), C.byref(h), C.byref(out)), w, h, out)
+
+
+def load_jpeg_file(path) -> np.ndarray:
+    w, h, out = C.c_int32(), C.c_int32(), C.c_void_p()
+    return _take_image(lib().rt_load_jpeg_file(os.fsencode(path), C.byref(w), C.byref(h), C.byref(out)), w, h, out)
 
 
 def _ptr(a):

@@ -78,6 +78,14 @@ class image_texture(custom_texture):
         self.texture_width, self.texture_height, self.texels = int(width), int(height), texels
 
 
+def load_texture(filename):
+    """load_texture of cuda/main.cu:385-436: a JPEG file -> image_texture.  Decoding is done by
+    the library (rt_load_jpeg_file), which reproduces the texels of the reference's stb_image."""
+    from . import api
+    texels = api.load_jpeg_file(filename)
+    return image_texture(texels.shape[1], texels.shape[0], texels)
+
+
 # ---- materials --------------------------------------------------------------------------
 
 class material:
