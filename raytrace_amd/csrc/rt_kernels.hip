@@ -79,8 +79,8 @@ __device__ __forceinline__ double sqrt_f64(double x) {
 // sphere.h:18-41 in double, unnormalised direction, parametric t.  A single-precision look at
 // the same quadratic first drops rays that miss beyond any rounding doubt: origin outside and
 // heading away, or discriminant negative by more than the float error bound.
-__device__ __forceinline__ bool wide_hit(const DWide& w, V3 o, V3 d, double t_min, double t_max, double& t_out) {
-    {
+__device__ __forceinline__ bool wide_hit(const DWide& w, V3 o, V3 d, double t_min, double t_max, bool far_only, double& t_out) {
+    if (!far_only) {
         float ox = o.x - (float)w.cx, oy = o.y - (float)w.cy, oz = o.z - (float)w.cz;
         float rr = (float)w.r * (float)w.r;
         float oo = fmaf(oz, oz, fmaf(oy, oy, ox * ox));
@@ -102,7 +102,7 @@ __device__ __forceinline__ bool wide_hit(const DWide& w, V3 o, V3 d, double t_mi
     double sq = sqrt_f64(disc);
     double inv_a = rcp_f64(a);
     double root = (-hb - sq) * inv_a;
-    if (root < t_min || root > t_max) {
+    if (far_only || root < t_min || root > t_max) {
         root = (-hb + sq) * inv_a;
         if (root < t_min || root > t_max) return false;
     }
@@ -113,7 +113,9 @@ __device__ __forceinline__ bool wide_hit(const DWide& w, V3 o, V3 d, double t_mi
 // Ordinary sphere against a unit direction: distance of the centre's foot point along the ray
 // (tca), squared distance of the centre from the ray line (l2), half chord (thc).  Works on
 // differences of nearby numbers only, so it stays accurate where b*b - 4ac cancels.
-__device__ __forceinline__ bool sphere_test(float4 s, V3 o, V3 dh, float tn_min, float tn_max, float& tn_out) {
+// lo_near / lo_far: smallest distance accepted for the near and the far root (both tn_min, except
+// on the sphere the ray starts on: see Origin).
+__device__ __forceinline__ bool sphere_test(float4 s, V3 o, V3 dh, float lo_near, float lo_far, float tn_max, float& tn_out) {
     V3 L = mk(s.x - o.x, s.y - o.y, s.z - o.z);
     float tca = dot(L, dh);
     V3 l = madd(L, -tca, dh);
@@ -122,13 +124,33 @@ __device__ __forceinline__ bool sphere_test(float4 s, V3 o, V3 dh, float tn_min,
     if (!(l2 <= r2)) return false;
     float thc = __builtin_amdgcn_sqrtf(r2 - l2);    // 1 ulp; the winner's root is polished in double
     float root = tca - thc;
-    if (!(root >= tn_min && root <= tn_max)) {
+    if (!(root >= lo_near && root <= tn_max)) {
         root = tca + thc;
-        if (!(root >= tn_min && root <= tn_max)) return false;
+        if (!(root >= lo_far && root <= tn_max)) return false;
     }
     tn_out = root;
     return true;
 }
+
+// The primitive a ray starts on, as the scatter that made the ray recorded it.  In exact
+// arithmetic such a ray meets that primitive again at t = 0 (rejected: below t_min) and, for a
+// sphere entered or crossed from inside, at the far side; the double-precision reference computes
+// exactly that.  The single-precision origin lies up to an ulp of its coordinates (3e-5 at
+// |p| = 500) off the surface, and a root that should be 0 can come out above t_min * |d|.  So:
+// a rect is not tested against the ray it emitted, a sphere left towards its outside is not
+// tested, a sphere left towards its inside takes only its far root.
+//   code < 0: none; else kind << 29 | inward << 28 | index   (kind 0 sphere, 1 wide sphere, 2 rect)
+struct Origin {
+    int code;
+    __device__ __forceinline__ int sphere() const { return (code >= 0 && (code >> 29) == 0) ? (code & 0x0fffffff) : -1; }
+    __device__ __forceinline__ int wide() const { return (code >= 0 && (code >> 29) == 1) ? (code & 0x0fffffff) : -1; }
+    __device__ __forceinline__ int rect() const { return (code >= 0 && (code >> 29) == 2) ? (code & 0x0fffffff) : -1; }
+    __device__ __forceinline__ bool inward() const { return (code >> 28) & 1; }
+};
+__device__ __forceinline__ Origin origin_of(int kind, int idx, bool inward) {
+    Origin g; g.code = (kind << 29) | ((inward ? 1 : 0) << 28) | idx; return g;
+}
+__device__ __forceinline__ Origin no_origin() { Origin g; g.code = -1; return g; }
 
 // cuda/sceneobject.h:84-88: a world-space ray seen from the instance (the translation comes off
 // first), in double and rounded once; `num` is the distance from the origin to the plane
@@ -219,12 +241,13 @@ struct GeoLds {
 
 template <bool COUNT, class G>
 __device__ __forceinline__ void leaf_spheres(const G& geo, int first, int count, V3 o, V3 dh,
-                                             float tn_min, Cand& best, Counters& cn) {
+                                             float tn_min, int self, Cand& best, Counters& cn) {
     for (int i = first; i < first + count; i++) {
         float4 s = geo.sphere(i);
         float tn;
         if (COUNT) cn.sph++;
-        if (sphere_test(s, o, dh, tn_min, best.tn, tn)) {
+        const float lo = i == self ? kInf : tn_min;    // the sphere the ray starts on is settled before the traversal
+        if (sphere_test(s, o, dh, lo, lo, best.tn, tn)) {
             int obj = geo.obj(i);
             if (COUNT) cn.sph_hit++;
             if (better(tn, obj, best)) { best.tn = tn; best.kind = 0; best.idx = i; best.obj = obj; }
@@ -255,20 +278,19 @@ __device__ __forceinline__ RayN normalise(V3 d, float t_min) {
 }
 
 // Always-tested primitives: wide spheres (double) and rects.  They run first and tighten the
-// distance bound the BVH traversal prunes with.  `from_rect` is the list position of the rect
-// the ray starts on (or -1): a ray that leaves a plane meets that plane again only at t = 0,
-// which the double-precision reference rejects as below t_min, while the float hit point lies
-// up to an ulp of its coordinates off the plane and a grazing ray would find it again.
+// distance bound the BVH traversal prunes with.
 template <bool COUNT>
-__device__ __forceinline__ void hit_always(const DScene& sc, V3 o, V3 d, const RayN& rn, float t_min, int from_rect,
+__device__ __forceinline__ void hit_always(const DScene& sc, V3 o, V3 d, const RayN& rn, float t_min, Origin from,
                                            Cand& best, Counters& cn) {
+    const int from_wide = from.wide(), from_rect = from.rect();
     for (int i = 0; i < sc.n_wide; i++) {
         const DWide w = sc.wide[i];
         double t;
         if (COUNT) cn.wide++;
+        if (i == from_wide && !from.inward()) continue;
         // only wide spheres have been seen so far: compare in double, later object wins a tie
         double tmax = best.kind < 0 ? (double)kInf : best.td;
-        if (wide_hit(w, o, d, (double)t_min, tmax, t) && (best.kind < 0 || t < best.td || w.obj > best.obj)) {
+        if (wide_hit(w, o, d, (double)t_min, tmax, i == from_wide, t) && (best.kind < 0 || t < best.td || w.obj > best.obj)) {
             best.tn = (float)(t * (double)rn.len); best.td = t; best.kind = 1; best.idx = i; best.obj = w.obj;
         }
     }
@@ -276,7 +298,7 @@ __device__ __forceinline__ void hit_always(const DScene& sc, V3 o, V3 d, const R
         const DRect r = sc.rects[i];
         float t;
         if (COUNT) cn.rect++;
-        if (r.obj == from_rect) continue;
+        if (i == from_rect) continue;
         ObjRay q;
         if (r.axes >> 8) {                   // instance: a rotation keeps |d|, so t means the same
             q = to_object(sc.xforms[(r.axes >> 8) - 1], o, d, r.axes & 3, r.k);
@@ -296,7 +318,9 @@ __device__ __forceinline__ void hit_always(const DScene& sc, V3 o, V3 d, const R
 // line than the radius?) and only a group in which some lane passes runs the full test.  The
 // array is padded to a multiple of four with spheres nothing can hit.
 template <bool COUNT>
-__device__ __forceinline__ void hit_list(const DScene& sc, V3 o, const RayN& rn, Cand& best, Counters& cn) {
+__device__ __forceinline__ void hit_list(const DScene& sc, V3 o, const RayN& rn, Origin from, Cand& best, Counters& cn) {
+    const int self = from.sphere();
+    const bool self_in = from.inward();
     // constant address space: tells the compiler nothing in the kernel writes these records, which
     // is what it needs to fetch them with scalar loads
     typedef const float __attribute__((address_space(4))) cfloat;
@@ -323,8 +347,9 @@ __device__ __forceinline__ void hit_list(const DScene& sc, V3 o, const RayN& rn,
             if (__ballot(gap[k] >= 0.0f) != 0ull) {
                 float thc = __builtin_amdgcn_sqrtf(fmaxf(gap[k], 0.0f));
                 float t0 = tca[k] - thc, t1 = tca[k] + thc;
-                bool ok0 = t0 >= rn.tn_min && t0 <= best.tn;
-                bool ok1 = t1 >= rn.tn_min && t1 <= best.tn;
+                const bool own = i + k == self;                   // the sphere this ray starts on
+                bool ok0 = t0 >= rn.tn_min && t0 <= best.tn && !own;
+                bool ok1 = t1 >= rn.tn_min && t1 <= best.tn && !(own && !self_in);
                 bool hit = gap[k] >= 0.0f && (ok0 || ok1);
                 if (COUNT && hit) cn.sph_hit++;
                 best.tn = hit ? (ok0 ? t0 : t1) : best.tn;
@@ -333,6 +358,19 @@ __device__ __forceinline__ void hit_list(const DScene& sc, V3 o, const RayN& rn,
                 best.obj = hit ? info[2 * (i + k)] : best.obj;
             }
         }
+    }
+}
+
+// The sphere a ray starts on, when the ray heads into it (refraction, internal reflection): only
+// its far side can be hit.  Settled here, before the traversal, which then skips that sphere.
+template <class G>
+__device__ __forceinline__ void hit_own_sphere(const G& geo, V3 o, const RayN& rn, Origin from, Cand& best) {
+    const int self = from.sphere();
+    if (self < 0 || !from.inward()) return;
+    float tn;
+    if (sphere_test(geo.sphere(self), o, rn.dh, kInf, rn.tn_min, best.tn, tn)) {
+        int obj = geo.obj(self);
+        if (better(tn, obj, best)) { best.tn = tn; best.kind = 0; best.idx = self; best.obj = obj; }
     }
 }
 
@@ -350,9 +388,10 @@ __device__ __forceinline__ void hit_list(const DScene& sc, V3 o, const RayN& rn,
 constexpr int kTravDone = (int)0x80000000;     // not a leaf code: ~kTravDone >> 2 exceeds any sphere count
 
 template <bool COUNT, bool SLICED, class G>
-__device__ __forceinline__ void hit_bvh(const G& geo, V3 o, const RayN& rn, int* stack, int budget,
+__device__ __forceinline__ void hit_bvh(const G& geo, V3 o, const RayN& rn, Origin from, int* stack, int budget,
                                         int& cur, int& sp, Cand& best, Counters& cn) {
     const V3 dh = rn.dh;
+    const int self = from.sphere();
     const float tn_min = rn.tn_min;
     const SlabRay sr = slab_ray(o, dh);
     int wave_steps = 0;                            // wave-uniform
@@ -387,7 +426,7 @@ __device__ __forceinline__ void hit_bvh(const G& geo, V3 o, const RayN& rn, int*
         if (cur < 0 && cur != kTravDone) {
             if (COUNT) { cn.steps++; if (first_active_lane()) cn.wave_steps++; }
             int code = ~cur;
-            leaf_spheres<COUNT>(geo, code >> 2, (code & 3) + 1, o, dh, tn_min, best, cn);
+            leaf_spheres<COUNT>(geo, code >> 2, (code & 3) + 1, o, dh, tn_min, self, best, cn);
             if (sp > 0) {
                 sp--;
                 cur = stack[sp * kBlock];
@@ -403,12 +442,12 @@ template <bool COUNT>
 __device__ __forceinline__ Cand closest_hit(const DScene& sc, V3 o, V3 d, float t_min, int* stack, Counters& cn) {
     Cand best = no_hit();
     RayN rn = normalise(d, t_min);
-    hit_always<COUNT>(sc, o, d, rn, t_min, -1, best, cn);
+    hit_always<COUNT>(sc, o, d, rn, t_min, no_origin(), best, cn);
     GeoGlobal geo = {sc.nodes, sc.sph, sc.sph_info};
-    if (!sc.use_bvh) hit_list<COUNT>(sc, o, rn, best, cn);
+    if (!sc.use_bvh) hit_list<COUNT>(sc, o, rn, no_origin(), best, cn);
     else if (sc.root != kNoBvh) {
         int cur = sc.root, sp = 0;
-        hit_bvh<COUNT, false>(geo, o, rn, stack, 0, cur, sp, best, cn);
+        hit_bvh<COUNT, false>(geo, o, rn, no_origin(), stack, 0, cur, sp, best, cn);
     }
     return best;
 }
@@ -420,6 +459,7 @@ struct Rec {
     float t;        // parametric
     float u, v;
     int front, mat, obj;
+    bool hollow;    // sphere of negative radius: its outward normal points at the centre
 };
 
 // cuda/sphere.h:20-26 on the unit outward normal.  theta = acos(-y) is taken as
@@ -451,6 +491,7 @@ __device__ __forceinline__ Rec make_record(const DScene& sc, const Cand& c, V3 o
     Rec r;
     r.obj = c.obj;
     r.u = 0.0f; r.v = 0.0f;
+    r.hollow = false;
     if (c.kind == 2) {
         const DRect q = sc.rects[c.idx];
         int ka = q.axes & 3, aa = (q.axes >> 2) & 3, ba = (q.axes >> 4) & 3;
@@ -490,9 +531,11 @@ __device__ __forceinline__ Rec make_record(const DScene& sc, const Cand& c, V3 o
         r.mat = sc.sph_info[c.idx].y;
         if (!refine) {
             float4 s = sc.sph[c.idx];
+            const float rad32 = (float)sc.sph64[c.idx].w;        // sph holds |r|
+            r.hollow = rad32 < 0.0f;
             r.t = tf;
             r.p = madd(o, tf, d);
-            V3 on = (1.0f / s.w) * mk(r.p.x - s.x, r.p.y - s.y, r.p.z - s.z);
+            V3 on = (1.0f / rad32) * mk(r.p.x - s.x, r.p.y - s.y, r.p.z - s.z);
             face(r, d, on);
             if (want_uv) sphere_uv_inst(sc, xform, on, r.u, r.v);
             return r;
@@ -515,6 +558,7 @@ __device__ __forceinline__ Rec make_record(const DScene& sc, const Cand& c, V3 o
             if (fabsf(corr) <= 1e-5f * fabsf(tf)) break;
         }
     }
+    r.hollow = rad < 0.0;
     double px = fma(t, (double)d.x, (double)o.x), py = fma(t, (double)d.y, (double)o.y), pz = fma(t, (double)d.z, (double)o.z);
     float inv_r = 1.0f / (float)rad;
     double ir = (double)inv_r;
@@ -710,7 +754,7 @@ __device__ __forceinline__ unsigned long long clk() { return __builtin_amdgcn_s_
 // L collects the path's radiance: emitted light along the way and the background at the end.
 template <bool COUNT>
 __device__ __forceinline__ bool shade(const DScene& sc, const DRender& rp, const Cand& c, const Key& key, int depth,
-                                      bool refine, const RayN& rn, V3& o, V3& d, V3& T, V3& L, int& from_rect, Counters& cn) {
+                                      bool refine, const RayN& rn, V3& o, V3& d, V3& T, V3& L, Origin& from, Counters& cn) {
     if (c.kind < 0) {
         L = L + T * background(sc, rn.dh);
         return true;
@@ -729,7 +773,10 @@ __device__ __forceinline__ bool shade(const DScene& sc, const DRender& rp, const
     T = T * att;
     o = r.p;
     d = sd;
-    from_rect = c.kind == 2 ? c.obj : -1;
+    // does the new ray head into the ball?  r.n faces against the old ray: it is the outward
+    // normal on a front face; a hollow sphere's outward normal points at its centre
+    const bool into = (dot(sd, r.n) < 0.0f) == ((r.front != 0) != r.hollow);
+    from = origin_of(c.kind, c.idx, into);
     return !cont || depth >= rp.max_depth;             // main.cc:13-14: the limit ends in black
 }
 
@@ -834,7 +881,7 @@ __global__ __launch_bounds__(kBlock, 5) void render_kernel(DScene sc, DCamera ca
     unsigned long long next = 0ull;                    // wave-uniform: first unit not handed out yet
     bool has = false;                                  // this lane is on a path
     int q = 0, depth = 0;                              // pixel of the tile, rays traced on the path
-    int from_rect = -1;                                // list position of the rect the ray starts on
+    Origin from = no_origin();                         // the primitive the ray starts on
     V3 o = mk(0, 0, 0), d = mk(0, 0, 1), T = mk(1, 1, 1), L = mk(0, 0, 0);
     // closest-hit query in progress: candidate so far and traversal position.  cur == kTravDone
     // on a lane with a path means "ray not started yet".
@@ -856,7 +903,7 @@ __global__ __launch_bounds__(kBlock, 5) void render_kernel(DScene sc, DCamera ca
                     T = mk(1.0f, 1.0f, 1.0f);
                     L = mk(0.0f, 0.0f, 0.0f);
                     depth = 0;
-                    from_rect = -1;
+                    from = no_origin();
                     nsamples++;
                     has = true;
                 }
@@ -878,17 +925,17 @@ __global__ __launch_bounds__(kBlock, 5) void render_kernel(DScene sc, DCamera ca
             int& spq = *(SLICED ? &sp : &sp_trip);
             if (curq == kTravDone) {                   // a new ray: always-tested primitives first
                 cq = no_hit();
-                hit_always<COUNT>(sc, o, d, rn, rp.t_min, from_rect, cq, cn);
+                hit_always<COUNT>(sc, o, d, rn, rp.t_min, from, cq, cn);
                 nrays++;
                 depth++;
-                if (!sc.use_bvh) hit_list<COUNT>(sc, o, rn, cq, cn);
-                else if (sc.root != kNoBvh) { curq = sc.root; spq = 0; }
+                if (!sc.use_bvh) hit_list<COUNT>(sc, o, rn, from, cq, cn);
+                else if (sc.root != kNoBvh) { hit_own_sphere(geo, o, rn, from, cq); curq = sc.root; spq = 0; }
             }
             if (PROF) { unsigned long long t = clk(); ph[1] += t - tq; tq = t; }
-            if (curq != kTravDone) hit_bvh<COUNT, SLICED>(geo, o, rn, stack, rp.slice, curq, spq, cq, cn);
+            if (curq != kTravDone) hit_bvh<COUNT, SLICED>(geo, o, rn, from, stack, rp.slice, curq, spq, cq, cn);
             if (PROF) { unsigned long long t = clk(); ph[2] += t - tq; tq = t; }
             if (curq == kTravDone) {                   // query finished (else: resumed next trip)
-                if (shade<COUNT>(sc, rp, cq, key, depth, refine, rn, o, d, T, L, from_rect, cn)) {
+                if (shade<COUNT>(sc, rp, cq, key, depth, refine, rn, o, d, T, L, from, cn)) {
                     atomicAdd(&accum[q * 3 + 0], to_fixed(L.x));
                     atomicAdd(&accum[q * 3 + 1], to_fixed(L.y));
                     atomicAdd(&accum[q * 3 + 2], to_fixed(L.z));

@@ -539,6 +539,77 @@ def procedural_image(width, height, seed=7):
     return np.stack([r, g, b], axis=-1)
 
 
+_SKYBOX_FILES = dict(earth="textures/earthmap.jpg", mars="textures/mars.jpg", sunset="textures/sunset.jpg",
+                     back="textures/skybox/back.jpg", bottom="textures/skybox/bottom.jpg", left="textures/skybox/left.jpg",
+                     front="textures/skybox/front.jpg", top="textures/skybox/top.jpg", right="textures/skybox/right.jpg")
+
+
+def skybox_textures(texture_dir=None):
+    """The nine textures of cuda/main.cu:494-503, loaded from `texture_dir` (the directory that
+    holds the reference's `textures/`), or deterministic stand-ins of small size when it is None."""
+    out = {}
+    for k, (name, rel) in enumerate(_SKYBOX_FILES.items()):
+        if texture_dir is not None:
+            out[name] = load_texture(os.path.join(texture_dir, rel))
+        else:
+            img = procedural_image(96, 48, seed=7 + 5 * k)
+            out[name] = image_texture(96, 48, img)
+    return out
+
+
+def skybox_scene(textures=None, num_small_balls=125, num_boxes=100, seed=1984):
+    """The world of the reference's GPU driver (create_world, cuda/main.cu:39-189): three large
+    and three small spheres (glass, metal, image-textured), a cluster of `num_boxes` r = 5 spheres
+    that the reference wraps in a bvh_node, a two-coloured box of six rects, `num_small_balls`
+    random spheres on the floor plane y = 248, the light, and a 555-unit cube of image-textured
+    emitters (lambertian_bg) as sky.  The reference rolls its random numbers with curand (seed
+    1984, cuda/main.cu:514); here they come from numpy's Philox, drawn in the same order, so the
+    layout is of the same kind, not the same numbers."""
+    t = textures if textures is not None else skybox_textures()
+    rnd = iter(_philox_uniforms(2 + 3 * num_boxes + 10 * num_small_balls, seed))
+    rng = lambda lo, hi: lo + (hi - lo) * next(rnd)                       # RND_IN_RANGE
+    light = diffuse_light((7, 7, 7))
+    white, red, green = lambertian((.73, .73, .73)), lambertian((.65, .05, .05)), lambertian((.12, .45, .15))
+    w = sceneobject_list()
+    main_x, main_z = rng(-4.0, 4.0), rng(-4.0, 4.0)
+    w.add(sphere((200, 278, 400), 30.0, dielectric(1.5)))
+    w.add(sphere((100, 278, 350), 30.0, metal((0.7, 0.6, 0.5), 0.0)))
+    w.add(sphere((250, 278, 500), 30.0, lambertian(t["earth"])))
+    w.add(sphere((230, 263, 300), 15.0, lambertian(t["mars"])))
+    w.add(sphere((300, 263, 400), 15.0, metal((0.96, 0.25, 0.25), 0.15)))
+    w.add(sphere((100, 315, 405), 15.0, lambertian(t["sunset"])))
+    cluster = sceneobject_list()
+    for _ in range(num_boxes):
+        cluster.add(sphere((rng(200, 250), rng(310, 360), rng(400, 450)), 5.0, white))
+    w.add(bvh_node(cluster))
+    w.add(box((90, 248, 395), (110, 300, 415), green, red))
+    for _ in range(num_small_balls):
+        choose, size = next(rnd), rng(5.0, 10.0)
+        x, z = rng(50, 400) + main_x + 1.0, rng(250, 550) + main_z + 1.0
+        u = [next(rnd) for _ in range(6)]
+        if choose < 0.8:
+            m = lambertian((u[0] * u[1], u[2] * u[3], u[4] * u[5]))
+        elif choose < 0.95:
+            m = metal((0.5 * (1 + u[0]), 0.5 * (1 + u[1]), 0.5 * (1 + u[2])), 0.5 * u[3])
+        else:
+            m = dielectric(1.5)
+        w.add(sphere((x, 248 + size, z), size, m))
+    d = 555
+    w.add(yz_rect(0, d, 0, d, d, lambertian_bg(t["left"])))
+    w.add(yz_rect(0, d, 0, d, 0, lambertian_bg(t["right"])))
+    w.add(xz_rect(75, 270, 76, 280, 554, light))
+    w.add(xz_rect(0, d, 0, d, 0, lambertian_bg(t["bottom"])))
+    w.add(xz_rect(0, d, 0, d, d, lambertian_bg(t["top"])))
+    w.add(xy_rect(0, d, 0, d, d, lambertian_bg(t["front"])))
+    w.add(xy_rect(0, d, 0, d, 0, lambertian_bg(t["back"])))
+    return w
+
+
+def skybox_camera(aspect_ratio):
+    """cuda/main.cu:182-187."""
+    return camera((450, 278, 200), (0, 278, 555), (0, 1, 0), 40.0, aspect_ratio, 0.0, 10.0)
+
+
 def stress_scene(n_spheres=1_000_000, seed=42, image=None):
     """BVH stress scene: centres uniform in [-500,500] x [0,50] x [-500,500], radii U(0.1,0.5),
     materials 80/15/5 % lambertian/metal/glass as main.cc:53-70; every tenth lambertian is

@@ -42,13 +42,15 @@ def test_primary_ray_hits_match_main_cc(ctx):
     assert p_err.max() <= 1e-5
 
 
-@pytest.mark.parametrize("name,bound", [("image_120x80_16spp.npz", 1e-3), ("image_240x160_64spp.npz", 1e-3)])
+@pytest.mark.parametrize("name,bound", [("image_120x80_16spp.npz", 5e-4), ("image_240x160_64spp.npz", 5e-4)])
 def test_keyed_stream_image_rmse(ctx, api, name, bound):
     """Same Philox stream through the unmodified ray_color (golden) and through the kernels:
     per-pixel RMSE of the mean radiance.  Independent seeds give 0.042 at 16 spp and 0.021 at
     64 spp on this scene and the naive-float restatement of the path sits at 0.005; the kernels
-    measure 1.8e-4 and 1.3e-4 (paths that cross a float-vs-double branch threshold diverge, the
-    rest agree to rounding), so the stated bound is 1e-3."""
+    measure 1.1e-4 and 1.2e-4 (paths that cross a float-vs-double branch threshold diverge, the
+    rest agree to rounding: under 1 % of the pixels differ by more than 1e-5), so the stated bound
+    is 5e-4.  The number of rays traced differs from the reference's by 31 of 419 123 and by 159
+    of 6 735 283."""
     g = load_golden(name)
     W, H, spp = int(g["W"]), int(g["H"]), int(g["spp"])
     img = ctx.render_host(api.Context.params(W, H, spp, int(g["depth"]), int(g["seed"])))
@@ -57,7 +59,7 @@ def test_keyed_stream_image_rmse(ctx, api, name, bound):
     mean = img[..., :3].astype(np.float64) / spp
     rmse = np.sqrt(np.mean((mean - g["sums"] / spp) ** 2))
     assert rmse <= bound, rmse
-    assert abs(st["rays"] - int(g["rays"])) / int(g["rays"]) < 0.002
+    assert abs(st["rays"] - int(g["rays"])) / int(g["rays"]) < 2e-4
     assert st["samples"] == W * H * spp
 
 

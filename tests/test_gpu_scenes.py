@@ -169,6 +169,34 @@ def test_textured_sphere_instance_turns_its_texture(api, S, oracle):
         ctx.close()
 
 
+# ---- the reference GPU driver's own world (cuda/main.cu:39-189) ------------------------------------------
+
+def test_skybox_world_of_the_reference_driver(api, S, oracle):
+    flat = S.flatten(S.skybox_scene(), background=S.RT_BG_SOLID, bg_color=(0, 0, 0))
+    assert flat.n_prims == 6 + 100 + 6 + 125 + 7
+    cam = S.skybox_camera(1.5).desc()
+    ctx = api.Context(0)
+    ctx.upload_scene(flat)
+    ctx.set_camera(**cam)
+    rng = np.random.default_rng(21)
+    cd = oracle.camera(**cam)
+    rays = [oracle.get_ray(cd, rng.random(), rng.random(), 3, k, 0)[0] for k in range(4000)]
+    for k in range(2000):
+        rays.append(np.concatenate([rng.uniform(20, 530, 3), _unit(rng.normal(size=3))]))
+    rays = _f32(np.array(rays))
+    want = oracle.trace(flat, rays)
+    hits = ctx.trace_primary(rays)
+    _check_hits(hits, want, uv_abs=2e-5, allow_id_mismatch=2)
+    assert len(np.unique(want["id"])) > 100
+    W, H, spp = 96, 64, 32
+    img = ctx.render_host(api.Context.params(W, H, spp, 50, 27))
+    sums, rays_n = oracle.render(flat, cd, W, H, spp, 50, 27, threads=8)
+    assert _rmse(img, sums, spp) <= 0.03, _rmse(img, sums, spp)
+    assert abs(ctx.stats()["rays"] - rays_n) / rays_n < 0.005
+    assert ctx.stats()["accel"] == api.RT_ACCEL_BVH
+    ctx.close()
+
+
 # ---- textures: checker (nested) and image, on spheres and rects -------------------------------------
 
 def _textured_world(S):
