@@ -270,8 +270,11 @@ struct RayN {
 };
 __device__ __forceinline__ RayN normalise(V3 d, float t_min) {
     RayN r;
-    r.len = sqrtf(dot(d, d));
-    r.inv_len = 1.0f / r.len;
+    // hardware reciprocal square root (1 ulp): a scale error e of dh enters the foot-point test
+    // only as e^2, and the winner's t is polished in double from (o, d) themselves
+    const float d2 = dot(d, d);
+    r.inv_len = __builtin_amdgcn_rsqf(d2);
+    r.len = d2 * r.inv_len;
     r.dh = r.inv_len * d;
     r.tn_min = t_min * r.len;
     return r;
@@ -487,7 +490,7 @@ __device__ __forceinline__ void face(Rec& r, V3 d, V3 outward) {
 // Fill the record of the winning candidate.  Ordinary spheres: Newton steps on
 // f(t) = a t^2 + 2 hb t + c in double from the single-precision root (the correction itself is
 // a float division), then p and the normal from the polished t.
-__device__ __forceinline__ Rec make_record(const DScene& sc, const Cand& c, V3 o, V3 d, bool refine, bool want_uv) {
+__device__ __forceinline__ Rec make_record(const DScene& sc, const Cand& c, V3 o, V3 d, float inv_len, bool refine, bool want_uv) {
     Rec r;
     r.obj = c.obj;
     r.u = 0.0f; r.v = 0.0f;
@@ -526,8 +529,7 @@ __device__ __forceinline__ Rec make_record(const DScene& sc, const Cand& c, V3 o
         xform = w.xform;
     } else {
         if (want_uv && sc.sph_xform) xform = sc.sph_xform[c.idx];
-        float len = sqrtf(dot(d, d));
-        float tf = c.tn / len;
+        float tf = c.tn * inv_len;
         r.mat = sc.sph_info[c.idx].y;
         if (!refine) {
             float4 s = sc.sph[c.idx];
@@ -553,14 +555,14 @@ __device__ __forceinline__ Rec make_record(const DScene& sc, const Cand& c, V3 o
             double f = fma(g + hb, t, cc);            // (a t + 2 hb) t + c
             float fp = 2.0f * (float)g;
             if (fp == 0.0f) break;
-            float corr = (float)f / fp;
+            float corr = (float)f * __builtin_amdgcn_rcpf(fp);
             t -= (double)corr;
             if (fabsf(corr) <= 1e-5f * fabsf(tf)) break;
         }
     }
     r.hollow = rad < 0.0;
     double px = fma(t, (double)d.x, (double)o.x), py = fma(t, (double)d.y, (double)o.y), pz = fma(t, (double)d.z, (double)o.z);
-    float inv_r = 1.0f / (float)rad;
+    float inv_r = __builtin_amdgcn_rcpf((float)rad);
     double ir = (double)inv_r;
     ir = ir * (2.0 - rad * ir);                       // one Newton step: 1/r to double accuracy
     V3 on = mk((float)((px - cx) * ir), (float)((py - cy) * ir), (float)((pz - cz) * ir));
@@ -661,7 +663,7 @@ __device__ __forceinline__ bool scatter(const DScene& sc, const DMaterial& m, V3
     switch (m.type) {
     case 0: {                                          // lambertian, material.h:21-32
         V3 s = rs;
-        V3 uvec = (1.0f / sqrtf(dot(s, s))) * s;       // vec3.h:139
+        V3 uvec = __builtin_amdgcn_rsqf(dot(s, s)) * s;   // vec3.h:139
         V3 dir = r.n + uvec;
         const float thr = 1e-8f;                       // vec3.h:64-68
         if (fabsf(dir.x) < thr && fabsf(dir.y) < thr && fabsf(dir.z) < thr) dir = r.n;
@@ -761,7 +763,7 @@ __device__ __forceinline__ bool shade(const DScene& sc, const DRender& rp, const
     }
     int mat = c.kind == 0 ? sc.sph_info[c.idx].y : (c.kind == 1 ? sc.wide[c.idx].mat : sc.rects[c.idx].mat);
     const DMaterial m = sc.mats[mat];
-    Rec r = make_record(sc, c, o, d, refine, m.tex >= 0);
+    Rec r = make_record(sc, c, o, d, rn.inv_len, refine, m.tex >= 0);
     V3 att, sd, em;
     if (COUNT) cn.shade++;
     // one Philox block per scatter segment, shared by whichever material consumes it
@@ -830,8 +832,10 @@ __global__ __launch_bounds__(kBlock, 5) void render_kernel(DScene sc, DCamera ca
     int* stack = s_dyn + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const int P = 64 / rp.lanes_per_pixel;             // pixels of this wave's tile
-    const int accum_words = 3 * P;                     // per wave: rgb per pixel of the tile
+    const int accum_words = 4 * P;                     // per wave: rgb sums per pixel of the tile (3P), then the tile's pixel table
     unsigned long long* accum = reinterpret_cast<unsigned long long*>(s_dyn + rp.stack_depth * kBlock) + (threadIdx.x >> 6) * accum_words;
+    // pixel table: (x, j) of the tile's q-th pixel, x = -1 where the tile hangs over the image
+    int2* tile_pix = reinterpret_cast<int2*>(accum + 3 * P);
     const auto geo = stage_geometry<LDS>(sc, s_dyn + rp.stack_depth * kBlock + (kBlock / 64) * accum_words * 2);
     __syncthreads();
 
@@ -874,7 +878,12 @@ __global__ __launch_bounds__(kBlock, 5) void render_kernel(DScene sc, DCamera ca
     if (tile >= n_tiles) break;
     const bool wave_ok = true;
     const int x0 = (int)(tile % (unsigned)tiles_x) * TW, ly0 = (int)(tile / (unsigned)tiles_x) * TH;
-    if (lane < P) { accum[lane * 3 + 0] = 0ull; accum[lane * 3 + 1] = 0ull; accum[lane * 3 + 2] = 0ull; }
+    if (lane < P) {
+        accum[lane * 3 + 0] = 0ull; accum[lane * 3 + 1] = 0ull; accum[lane * 3 + 2] = 0ull;
+        const int x = x0 + (lane % TW), ly = ly0 + (lane / TW);
+        const int j = (rp.tile_first + (ly / rp.tile_rows) * rp.tile_step) * rp.tile_rows + (ly % rp.tile_rows);
+        tile_pix[lane] = make_int2((x < rp.width && ly < rp.rows && j < rp.height) ? x : -1, j);
+    }
     __builtin_amdgcn_wave_barrier();                   // LDS serves one wave's accesses in issue order
 
     const unsigned long long total = (rp.max_depth > 0) ? ((unsigned long long)rp.spp << logP) : 0ull;
@@ -894,9 +903,9 @@ __global__ __launch_bounds__(kBlock, 5) void render_kernel(DScene sc, DCamera ca
             const unsigned long long u = next + (unsigned long long)__builtin_amdgcn_mbcnt_hi((unsigned)(need >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)need, 0u));
             if (!has && u < total) {
                 q = (int)(u & (unsigned long long)(P - 1));
-                const int x = x0 + (q % TW), ly = ly0 + (q / TW);
-                const int j = (rp.tile_first + (ly / rp.tile_rows) * rp.tile_step) * rp.tile_rows + (ly % rp.tile_rows);
-                if (x < rp.width && ly < rp.rows && j < rp.height) {
+                const int2 xj = tile_pix[q];
+                const int x = xj.x, j = xj.y;
+                if (x >= 0) {
                     key.pixel = (uint32_t)(j * rp.width + x);
                     key.sample = (uint32_t)rp.sample_begin + (uint32_t)(u >> logP);
                     camera_ray(cam, rp, key, x, j, o, d);
@@ -996,7 +1005,7 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(DScene sc, const float* _
         h.id = -1; h.t = 0.0f; h.front = 0; h.u = 0.0f; h.v = 0.0f;
         for (int a = 0; a < 3; a++) { h.p[a] = 0.0f; h.n[a] = 0.0f; }
     } else {
-        Rec r = make_record(sc, c, o, d, (flags & 2u) == 0u, true);
+        Rec r = make_record(sc, c, o, d, normalise(d, t_min).inv_len, (flags & 2u) == 0u, true);
         h.id = r.obj; h.t = r.t; h.front = r.front; h.u = r.u; h.v = r.v;
         h.p[0] = r.p.x; h.p[1] = r.p.y; h.p[2] = r.p.z;
         h.n[0] = r.n.x; h.n[1] = r.n.y; h.n[2] = r.n.z;
@@ -1042,7 +1051,7 @@ hipError_t launch_render(const DScene& sc, const DCamera& cam, const DRender& rp
     // and the sphere list
     DRender r = rp;
     r.stack_depth = sc.use_bvh ? sc.bvh_depth + 1 : 1;   // one push per inner level at most
-    size_t lds = (size_t)r.stack_depth * kBlock * sizeof(int) + (size_t)(kBlock / 64) * 3 * (64 / rp.lanes_per_pixel) * sizeof(unsigned long long);
+    size_t lds = (size_t)r.stack_depth * kBlock * sizeof(int) + (size_t)(kBlock / 64) * 4 * (64 / rp.lanes_per_pixel) * sizeof(unsigned long long);
     const size_t geo_bytes = (size_t)sc.n_nodes * 64 + (size_t)sc.n_sph * 20;
     const bool in_lds = (rp.flags & 32u) == 0u && sc.use_bvh && sc.n_sph > 0 && lds + geo_bytes <= 40 * 1024;
     if (in_lds) lds += geo_bytes;
