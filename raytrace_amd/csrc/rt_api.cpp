@@ -166,7 +166,7 @@ int validate_render(rt_context* ctx, const rt_render_params* p, rt::DRender* rp)
     rp->inv_hm1 = (float)(1.0 / (double)(p->height - 1));
     {
         const char* v = std::getenv("RT_TUNE_SLICE");
-        rp->slice = v && *v ? std::atoi(v) : -1;      // -1: chosen at launch from the tree depth
+        rp->slice = v && *v ? std::atoi(v) : 0x7fffffff;      // 0x7fffffff: chosen at launch from the tree depth
     }
     return RT_OK;
 }
@@ -455,6 +455,7 @@ int rt_upload_scene(rt_context* ctx, const rt_scene_desc* d) {
     s.root = root;
     s.bvh_depth = depth;
     s.use_bvh = use_bvh ? 1 : 0;
+    s.ids_fit_16 = (d->n_prims < 65536 && d->n_mats < 65536) ? 1 : 0;
     s.n_wide = (int)wide.size();
     s.n_rects = (int)rects.size();
     s.background = d->background;

@@ -66,6 +66,7 @@ struct DScene {
     int root;             // inner index, leaf code, or kNoBvh
     int bvh_depth;
     int use_bvh;          // 0: scan all ordinary spheres in order
+    int ids_fit_16;       // every list position and material index is below 65536
     const DWide* wide;
     int n_wide;
     const DRect* rects;
@@ -99,7 +100,7 @@ struct DRender {
     int lanes_per_pixel;                    // K: power of two, 1..64; a wave's tile holds 64/K pixels
     float inv_wm1, inv_hm1;                 // 1/(W-1), 1/(H-1)  (main.cc:117-118)
     int stack_depth;                        // entries per lane of the LDS traversal stack
-    int slice;                              // node steps a wave spends on traversal per trip (0 = no limit, < 0 = choose)
+    int slice;                              // node steps a wave spends on traversal per trip (0 = no limit, 0x7fffffff = choose at launch)
 };
 
 // counters[0] rays, [1] samples, [2] box tests, [3] sphere tests, [4] sphere hits,

@@ -237,12 +237,15 @@ struct GeoGlobal {
     __device__ __forceinline__ float4 node(int i, int q) const { return nodes[4 * (size_t)i + q]; }
     __device__ __forceinline__ float4 sphere(int i) const { return sph[i]; }
     __device__ __forceinline__ int obj(int i) const { return info[i].x; }
+    __device__ __forceinline__ int mat(int i) const { return info[i].y; }
 };
 struct GeoLds {
     const float4* nodes; const float4* sph; const int* objs;     // all three point into LDS
     __device__ __forceinline__ float4 node(int i, int q) const { return nodes[4 * i + q]; }
     __device__ __forceinline__ float4 sphere(int i) const { return sph[i]; }
-    __device__ __forceinline__ int obj(int i) const { return objs[i]; }
+    // list position and material share a word (both below 65536 in a scene that fits in LDS)
+    __device__ __forceinline__ int obj(int i) const { return objs[i] & 0xffff; }
+    __device__ __forceinline__ int mat(int i) const { return (int)((unsigned)objs[i] >> 16); }
 };
 
 template <bool COUNT, class G>
@@ -498,7 +501,9 @@ __device__ __forceinline__ void face(Rec& r, V3 d, V3 outward) {
 // Fill the record of the winning candidate.  Ordinary spheres: Newton steps on
 // f(t) = a t^2 + 2 hb t + c in double from the single-precision root (the correction itself is
 // a float division), then p and the normal from the polished t.
-__device__ __forceinline__ Rec make_record(const DScene& sc, const Cand& c, V3 o, V3 d, float inv_len, bool refine, bool want_uv) {
+// `s64` is the winning ordinary sphere in double and `mat` its material, both loaded by the caller.
+__device__ __forceinline__ Rec make_record(const DScene& sc, const Cand& c, V3 o, V3 d, float inv_len, bool refine, bool want_uv,
+                                           double4 s64, int mat) {
     Rec r;
     r.obj = c.obj;
     r.u = 0.0f; r.v = 0.0f;
@@ -538,10 +543,10 @@ __device__ __forceinline__ Rec make_record(const DScene& sc, const Cand& c, V3 o
     } else {
         if (want_uv && sc.sph_xform) xform = sc.sph_xform[c.idx];
         float tf = c.tn * inv_len;
-        r.mat = sc.sph_info[c.idx].y;
+        r.mat = mat;
         if (!refine) {
             float4 s = sc.sph[c.idx];
-            const float rad32 = (float)sc.sph64[c.idx].w;        // sph holds |r|
+            const float rad32 = (float)s64.w;                    // sph holds |r|
             r.hollow = rad32 < 0.0f;
             r.t = tf;
             r.p = madd(o, tf, d);
@@ -550,8 +555,7 @@ __device__ __forceinline__ Rec make_record(const DScene& sc, const Cand& c, V3 o
             if (want_uv) sphere_uv_inst(sc, xform, on, r.u, r.v);
             return r;
         }
-        double4 s = sc.sph64[c.idx];
-        cx = s.x; cy = s.y; cz = s.z; rad = s.w;
+        cx = s64.x; cy = s64.y; cz = s64.z; rad = s64.w;
         double ocx = (double)o.x - cx, ocy = (double)o.y - cy, ocz = (double)o.z - cz;
         double dx = d.x, dy = d.y, dz = d.z;
         double a = dx * dx + dy * dy + dz * dz;
@@ -762,20 +766,23 @@ __device__ __forceinline__ unsigned long long clk() { return __builtin_amdgcn_s_
 
 // Shade one finished closest-hit query: returns true when the path ended (sample complete).
 // L collects the path's radiance: emitted light along the way and the background at the end.
-template <bool COUNT>
-__device__ __forceinline__ bool shade(const DScene& sc, const DRender& rp, const Cand& c, const Key& key, int depth,
+template <bool COUNT, class G>
+__device__ __forceinline__ bool shade(const DScene& sc, const G& geo, const DRender& rp, const Cand& c, const Key& key, int depth,
                                       bool refine, const RayN& rn, V3& o, V3& d, V3& T, V3& L, Origin& from, Counters& cn) {
     if (c.kind < 0) {
         L = L + T * background(sc, rn.dh);
         return true;
     }
-    int mat = c.kind == 0 ? sc.sph_info[c.idx].y : (c.kind == 1 ? sc.wide[c.idx].mat : sc.rects[c.idx].mat);
+    // the loads the record and the material need go out first; the Philox block below is pure
+    // arithmetic and runs while they are in flight
+    const int mat = c.kind == 0 ? geo.mat(c.idx) : (c.kind == 1 ? sc.wide[c.idx].mat : sc.rects[c.idx].mat);
+    const double4 s64 = c.kind == 0 ? sc.sph64[c.idx] : make_double4(0.0, 0.0, 0.0, 1.0);
     const DMaterial m = sc.mats[mat];
-    Rec r = make_record(sc, c, o, d, rn.inv_len, refine, m.tex >= 0);
-    V3 att, sd, em;
-    if (COUNT) cn.shade++;
     // one Philox block per scatter segment, shared by whichever material consumes it
     const uint4 w = philox4x32_10(key.pixel, key.sample, (uint32_t)depth, 0u, key.seed_lo, key.seed_hi);
+    Rec r = make_record(sc, c, o, d, rn.inv_len, refine, m.tex >= 0, s64, mat);
+    V3 att, sd, em;
+    if (COUNT) cn.shade++;
     V3 rs = mk(0.0f, 0.0f, 0.0f);
     if (m.type == 0 || (m.type == 1 && m.fuzz > 0.0f)) rs = in_unit_sphere(w);
     bool cont = scatter(sc, m, rn.dh, r, w, rs, att, sd, em);
@@ -803,7 +810,7 @@ __device__ __forceinline__ typename GeoOf<LDS>::type stage_geometry(const DScene
         float4* sph = nodes + 4 * sc.n_nodes;
         int* objs = reinterpret_cast<int*>(sph + sc.n_sph);
         for (int i = threadIdx.x; i < 4 * sc.n_nodes; i += kBlock) nodes[i] = sc.nodes[i];
-        for (int i = threadIdx.x; i < sc.n_sph; i += kBlock) { sph[i] = sc.sph[i]; objs[i] = sc.sph_info[i].x; }
+        for (int i = threadIdx.x; i < sc.n_sph; i += kBlock) { sph[i] = sc.sph[i]; int2 f = sc.sph_info[i]; objs[i] = f.x | (f.y << 16); }
         GeoLds g = {nodes, sph, objs};
         return g;
     } else {
@@ -952,7 +959,7 @@ __global__ __launch_bounds__(kBlock, 5) void render_kernel(DScene sc, DCamera ca
             if (curq != kTravDone) hit_bvh<COUNT, SLICED>(geo, o, rn, from, stack, rp.slice, curq, spq, cq, cn);
             if (PROF) { unsigned long long t = clk(); ph[2] += t - tq; tq = t; }
             if (curq == kTravDone) {                   // query finished (else: resumed next trip)
-                if (shade<COUNT>(sc, rp, cq, key, depth, refine, rn, o, d, T, L, from, cn)) {
+                if (shade<COUNT>(sc, geo, rp, cq, key, depth, refine, rn, o, d, T, L, from, cn)) {
                     atomicAdd(&accum[q * 3 + 0], to_fixed(L.x));
                     atomicAdd(&accum[q * 3 + 1], to_fixed(L.y));
                     atomicAdd(&accum[q * 3 + 2], to_fixed(L.z));
@@ -1013,7 +1020,8 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(DScene sc, const float* _
         h.id = -1; h.t = 0.0f; h.front = 0; h.u = 0.0f; h.v = 0.0f;
         for (int a = 0; a < 3; a++) { h.p[a] = 0.0f; h.n[a] = 0.0f; }
     } else {
-        Rec r = make_record(sc, c, o, d, normalise(d, t_min).inv_len, (flags & 2u) == 0u, true);
+        const double4 s64 = c.kind == 0 ? sc.sph64[c.idx] : make_double4(0.0, 0.0, 0.0, 1.0);
+        Rec r = make_record(sc, c, o, d, normalise(d, t_min).inv_len, (flags & 2u) == 0u, true, s64, c.kind == 0 ? sc.sph_info[c.idx].y : 0);
         h.id = r.obj; h.t = r.t; h.front = r.front; h.u = r.u; h.v = r.v;
         h.p[0] = r.p.x; h.p[1] = r.p.y; h.p[2] = r.p.z;
         h.n[0] = r.n.x; h.n[1] = r.n.y; h.n[2] = r.n.z;
@@ -1061,14 +1069,14 @@ hipError_t launch_render(const DScene& sc, const DCamera& cam, const DRender& rp
     r.stack_depth = sc.use_bvh ? sc.bvh_depth + 1 : 1;   // one push per inner level at most
     size_t lds = (size_t)r.stack_depth * kBlock * sizeof(int) + (size_t)(kBlock / 64) * 4 * (64 / rp.lanes_per_pixel) * sizeof(unsigned long long);
     const size_t geo_bytes = (size_t)sc.n_nodes * 64 + (size_t)sc.n_sph * 20;
-    const bool in_lds = (rp.flags & 32u) == 0u && sc.use_bvh && sc.n_sph > 0 && lds + geo_bytes <= 40 * 1024;
+    const bool in_lds = (rp.flags & 32u) == 0u && sc.use_bvh && sc.n_sph > 0 && lds + geo_bytes <= 40 * 1024 && sc.ids_fit_16;
     if (in_lds) lds += geo_bytes;
     const bool count = (rp.flags & 4u) != 0u;
     const bool prof = (rp.flags & 8u) != 0u;
     dim3 grid((unsigned)blocks), block(kBlock);
     // Deep trees (large scenes) have a long-tailed traversal length: there a wave spends at most
     // `slice` node steps per trip on traversal and unfinished lanes resume on the next trip.
-    if (r.slice < 0) r.slice = sc.bvh_depth > 12 ? 32 : 0;
+    if (r.slice == 0x7fffffff) r.slice = sc.bvh_depth > 12 ? 32 : 0;
     const bool sliced = sc.use_bvh && r.slice > 0;
 #define RT_LAUNCH(...) hipLaunchKernelGGL((render_kernel<__VA_ARGS__>), grid, block, lds, stream, sc, cam, r, out, counters)
 #define RT_LAUNCH_S(C, L, P) do { if (sliced) RT_LAUNCH(C, L, P, true); else RT_LAUNCH(C, L, P, false); } while (0)
