@@ -384,7 +384,10 @@ int rt_upload_scene(rt_context* ctx, const rt_scene_desc* d) {
     std::vector<int32_t> order((size_t)ns);
     for (int64_t i = 0; i < ns; i++) order[i] = (int32_t)i;
     if (use_bvh && !device_build) {
-        bvh = rt::build_bvh(sc_c.data(), sc_r.data(), ns, rt::kMaxStack - 4);
+        const char* lm = std::getenv("RT_TUNE_LEAF_MAX");
+        const char* nc = std::getenv("RT_TUNE_NODE_COST");
+        bvh = rt::build_bvh(sc_c.data(), sc_r.data(), ns, rt::kMaxStack - 4, lm && *lm ? std::atoi(lm) : 4,
+                            nc && *nc ? (float)std::atof(nc) : 0.0f);
         if (bvh.depth > rt::kMaxStack - 2) return fail(ctx, RT_ERR_UNSUPPORTED, "BVH deeper than the traversal stack");
         order = bvh.order;
     }

@@ -24,7 +24,6 @@ struct Box {
 };
 
 constexpr int kBins = 16;
-constexpr int kLeafMax = 4;
 
 struct Builder {
     std::vector<Box> boxes;          // per input sphere, padded outwards
@@ -33,6 +32,8 @@ struct Builder {
     std::vector<float> nodes;
     int max_depth = 44;
     int depth_seen = 0;
+    int leaf_max = 4;                // a range of at most this many spheres may become a leaf
+    float node_cost = 0.0f;          // cost of visiting an inner node in units of one sphere test; 0: split down to leaf_max
 
     static int ceil_log2(int64_t v) {
         int l = 0;
@@ -41,18 +42,14 @@ struct Builder {
     }
 
     int32_t leaf_code(int64_t first, int64_t count) const {
-        return ~(int32_t)((first << 2) | (count - 1));
+        return ~(int32_t)((first << kLeafBits) | (count - 1));
     }
 
     // Builds the subtree over order[first, first+count); returns its child code and bounds.
     int32_t build(int64_t first, int64_t count, int depth, Box& bounds) {
         bounds.reset();
         for (int64_t i = first; i < first + count; i++) bounds.grow(boxes[order[i]]);
-        if (count <= kLeafMax) {
-            // a leaf of up to four spheres; SAH below may still have preferred to split it,
-            // but a 4-wide leaf costs less than the extra node fetch
-            return leaf_code(first, count);
-        }
+        if (count <= leaf_max && (node_cost <= 0.0f || count <= 2)) return leaf_code(first, count);
 
         float clo[3], chi[3];
         for (int a = 0; a < 3; a++) { clo[a] = std::numeric_limits<float>::infinity(); chi[a] = -clo[a]; }
@@ -63,7 +60,7 @@ struct Builder {
             }
 
         int64_t mid = -1;
-        bool balanced = depth + ceil_log2((count + kLeafMax - 1) / kLeafMax) + 1 >= max_depth;
+        bool balanced = depth + ceil_log2((count + leaf_max - 1) / leaf_max) + 1 >= max_depth;
         if (!balanced) {
             float best_cost = std::numeric_limits<float>::infinity();
             int best_axis = -1, best_bin = -1;
@@ -92,6 +89,13 @@ struct Builder {
                     if (cost < best_cost) { best_cost = cost; best_axis = a; best_bin = b; }
                 }
             }
+            // surface-area heuristic: a leaf costs one sphere test per sphere; splitting costs the
+            // node visit plus each side's tests weighted by the chance of entering it
+            if (count <= leaf_max && node_cost > 0.0f && best_axis >= 0) {
+                float split_cost = node_cost + best_cost / std::max(bounds.half_area(), 1e-30f);
+                if ((float)count <= split_cost) return leaf_code(first, count);
+            }
+            if (count <= leaf_max && best_axis < 0) return leaf_code(first, count);
             if (best_axis >= 0) {
                 float ext = chi[best_axis] - clo[best_axis];
                 float scale = (float)kBins / ext;
@@ -135,11 +139,13 @@ struct Builder {
 
 }  // namespace
 
-BvhResult build_bvh(const double* centers, const double* radii, int64_t n, int max_depth) {
+BvhResult build_bvh(const double* centers, const double* radii, int64_t n, int max_depth, int leaf_max, float node_cost) {
     BvhResult res;
     if (n <= 0) return res;
     Builder b;
     b.max_depth = max_depth;
+    b.leaf_max = leaf_max < 1 ? 1 : (leaf_max > kLeafCap ? kLeafCap : leaf_max);
+    b.node_cost = node_cost;
     b.boxes.resize((size_t)n);
     b.centroid.resize(3 * (size_t)n);
     b.order.resize((size_t)n);

@@ -13,6 +13,7 @@
 // catastrophically in float and is solved in double exactly as sphere.h:23-41 writes it, and
 // (b) a double-precision Newton polish of the winning ordinary sphere's root, so that hit
 // distance and normal agree with the double-precision reference to float rounding.
+#include "rt_bvh.h"
 #include "rt_device.h"
 #include "rt_philox.h"
 
@@ -440,7 +441,7 @@ __device__ __forceinline__ void hit_bvh(const G& geo, V3 o, const RayN& rn, Orig
         if (cur < 0 && cur != kTravDone) {
             if (COUNT) { cn.steps++; if (first_active_lane()) cn.wave_steps++; }
             int code = ~cur;
-            leaf_spheres<COUNT>(geo, code >> 2, (code & 3) + 1, o, dh, tn_min, self, best, cn);
+            leaf_spheres<COUNT>(geo, code >> kLeafBits, (code & (kLeafCap - 1)) + 1, o, dh, tn_min, self, best, cn);
             if (sp > 0) {
                 sp--;
                 cur = stack[sp * kBlock];

@@ -12,6 +12,8 @@
 //   assemble    64-byte nodes holding both children's boxes (layout: rt_device.h)
 #include "rt_lbvh.h"
 
+#include "rt_bvh.h"
+
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -235,11 +237,11 @@ __global__ __launch_bounds__(kThreads) void assemble_kernel(int n, const int2* _
     for (int side = 0; side < 2; side++) {
         int c = side == 0 ? ch.x : ch.y;
         int u;
-        if (c < 0) { u = (n - 1) + ~c; code[side] = ~(((~c) << 2) | 0); }
+        if (c < 0) { u = (n - 1) + ~c; code[side] = ~(((~c) << kLeafBits) | 0); }
         else {
             u = c;
             if (kept[c]) code[side] = newidx[c];
-            else { int2 r = range[c]; code[side] = ~((r.x << 2) | (r.y - r.x)); }
+            else { int2 r = range[c]; code[side] = ~((r.x << kLeafBits) | (r.y - r.x)); }
         }
 #pragma unroll
         for (int a = 0; a < 6; a++) bx[side][a] = __uint_as_float(kbox[6 * (size_t)u + a]);
