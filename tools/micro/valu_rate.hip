@@ -70,6 +70,12 @@ KERNEL(k_dfma, DECL_D, OP_DFMA) KERNEL(k_dmul, DECL_D, OP_DMUL) KERNEL(k_dadd, D
 #define OP_MULLO(x) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(x) : "v"(ia))
 #define OP_MULHI(x) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(x) : "v"(ia))
 #define OP_ALIGN(x) asm volatile("v_alignbit_b32 %0, %0, %0, 13" : "+v"(x))
+#define OP_MAD64(x) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(x) : "v"(ia), "v"(ib) : "vcc")
+#define DECL_L unsigned long long x0 = threadIdx.x, x1 = x0 + 1, x2 = x0 + 2, x3 = x0 + 3, x4 = x0 + 4, x5 = x0 + 5, x6 = x0 + 6, x7 = x0 + 7; unsigned ia = (unsigned)a + 3, ib = (unsigned)b + 5
+KERNEL(k_mad64, DECL_L, OP_MAD64)
+#define OP_CVT(x) asm volatile("v_cvt_f32_u32 %0, %0" : "+v"(x))
+#define OP_CVTW(x) asm volatile("v_cvt_f32_u32_sdwa %0, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "+v"(x))
+KERNEL(k_cvt, DECL_I, OP_CVT) KERNEL(k_cvtw, DECL_I, OP_CVTW)
 KERNEL(k_iadd, DECL_I, OP_IADD) KERNEL(k_and, DECL_I, OP_AND) KERNEL(k_xor, DECL_I, OP_XOR3) KERNEL(k_lshladd, DECL_I, OP_LSHLADD)
 KERNEL(k_mullo, DECL_I, OP_MULLO) KERNEL(k_mulhi, DECL_I, OP_MULHI) KERNEL(k_align, DECL_I, OP_ALIGN)
 
@@ -104,6 +110,7 @@ int main() {
     run("v_pk_fma_f32", k_pkfma, w, 4); run("v_pk_mul_f32", k_pkmul, w, 2); run("v_pk_add_f32", k_pkadd, w, 2);
     run("v_fma_f64", k_dfma, w, 2); run("v_mul_f64", k_dmul, w, 1); run("v_add_f64", k_dadd, w, 1);
     run("v_add_u32", k_iadd, w, 0); run("v_and_b32", k_and, w, 0); run("v_xor_b32", k_xor, w, 0); run("v_lshl_add", k_lshladd, w, 0);
+    run("v_mad_u64_u32", k_mad64, w, 0); run("v_cvt_f32_u32", k_cvt, w, 0); run("v_cvt_f32_u32 sdwa", k_cvtw, w, 0);
     run("v_mul_lo_u32", k_mullo, w, 0); run("v_mul_hi_u32", k_mulhi, w, 0); run("v_alignbit", k_align, w, 0);
     return 0;
 }
