@@ -351,7 +351,7 @@ int rt_upload_scene(rt_context* ctx, const rt_scene_desc* d) {
             }
             if (std::fabs(g[3]) > wide_radius) {
                 rt::DWide w{};
-                w.cx = c[0]; w.cy = c[1]; w.cz = c[2]; w.r = g[3]; w.obj = i; w.mat = mat; w.xform = xf + 1;
+                w.cx = c[0]; w.cy = c[1]; w.cz = c[2]; w.r = g[3]; w.r2 = g[3] * g[3]; w.obj = i; w.mat = mat; w.xform = xf + 1;
                 wide.push_back(w);
             } else {
                 sc_c.insert(sc_c.end(), c, c + 3); sc_r.push_back(g[3]);

@@ -13,11 +13,13 @@ namespace rt {
 // The same sphere in double for the polish of the winning hit: (cx, cy, cz, r).     32 B
 // Its list position and material: (obj, mat).                                        8 B
 
-struct DWide {            // sphere too large for single precision; always tested, in double
+struct DWide {            // sphere too large for the single-precision test; always tested
     double cx, cy, cz, r; // centre already in world space
+    double r2;            // r * r
     int obj, mat;
     int xform;            // 0, or 1 + index of the instance transform (only turns the texture coordinates)
     int pad1;
+    double pad2;
 };
 
 // Instance transform (cuda/sceneobject.h:31-109 plus a translation):

@@ -49,7 +49,6 @@ __device__ __forceinline__ bool first_active_lane() {
 
 struct Cand {
     float tn;     // distance along the unit direction (= t * |d|)
-    double td;    // parametric t in double, for wide spheres
     int kind;     // -1 none, 0 ordinary sphere, 1 wide sphere, 2 rect
     int idx;      // index into the kind's array
     int obj;      // list position: exact ties go to the later object (sceneobject_list.h:31-36
@@ -60,54 +59,30 @@ __device__ __forceinline__ bool better(float tn, int obj, const Cand& b) {
     return tn < b.tn || (tn == b.tn && obj > b.obj);
 }
 
-// 1/x and sqrt(x) in double from the single-precision hardware estimate plus Newton steps
-// (a few fused multiply-adds instead of the library's division and square-root sequences).
-__device__ __forceinline__ double rcp_f64(double x) {
-    double y = (double)(1.0f / (float)x);
-    y = y * fma(-x, y, 2.0);
-    y = y * fma(-x, y, 2.0);
-    return y;
-}
-__device__ __forceinline__ double sqrt_f64(double x) {
-    if (!(x > 1e-30)) return 0.0;
-    double r = (double)rsqrtf((float)x);
-    r = r * fma(-0.5 * x * r, r, 1.5);
-    r = r * fma(-0.5 * x * r, r, 1.5);
-    double s = x * r;
-    return fma(0.5 * r, fma(-s, s, x), s);
-}
-
-// sphere.h:18-41 in double, unnormalised direction, parametric t.  A single-precision look at
-// the same quadratic first drops rays that miss beyond any rounding doubt: origin outside and
-// heading away, or discriminant negative by more than the float error bound.
-__device__ __forceinline__ bool wide_hit(const DWide& w, V3 o, V3 d, double t_min, double t_max, bool far_only, double& t_out) {
-    if (!far_only) {
-        float ox = o.x - (float)w.cx, oy = o.y - (float)w.cy, oz = o.z - (float)w.cz;
-        float rr = (float)w.r * (float)w.r;
-        float oo = fmaf(oz, oz, fmaf(oy, oy, ox * ox));
-        float af = fmaf(d.z, d.z, fmaf(d.y, d.y, d.x * d.x));
-        float hbf = fmaf(oz, d.z, fmaf(oy, d.y, ox * d.x));
-        float cf = oo - rr;
-        float scale = oo + rr;
-        bool outside = cf > 1e-4f * scale;
-        if (outside && hbf > 1e-4f * sqrtf(oo * af)) return false;
-        if (outside && fmaf(hbf, hbf, -af * cf) < -1e-4f * af * scale) return false;
-    }
-    double ocx = (double)o.x - w.cx, ocy = (double)o.y - w.cy, ocz = (double)o.z - w.cz;
-    double dx = d.x, dy = d.y, dz = d.z;
-    double a = fma(dz, dz, fma(dy, dy, dx * dx));
-    double hb = fma(ocz, dz, fma(ocy, dy, ocx * dx));
-    double c = fma(ocz, ocz, fma(ocy, ocy, ocx * ocx)) - w.r * w.r;
-    double disc = fma(hb, hb, -a * c);          // (b*b - 4ac) / 4
+// Sphere too large for the single-precision test (sphere.h:18-41), against the unit direction.
+// What single precision cannot do here is form |o - c|^2 - r^2 and (o - c).d without losing the
+// answer to cancellation (r = 1000: 0.06 of absolute error on a difference of a few units), so
+// those three sums and the discriminant are taken in double (13 operations).  The roots then
+// come from the cancellation-free form of the quadratic formula, q = -(hb + sign(hb) sqrt(disc)),
+// roots q and c / q, in single precision: each is good to a few ulps, like an ordinary sphere's,
+// and the winner is polished in double like an ordinary sphere's.
+__device__ __forceinline__ bool wide_hit(const DWide& w, V3 o, V3 dh, float tn_min, float tn_max, bool far_only, float& tn_out) {
+    const double ocx = (double)o.x - w.cx, ocy = (double)o.y - w.cy, ocz = (double)o.z - w.cz;
+    const double hb = fma(ocz, (double)dh.z, fma(ocy, (double)dh.y, ocx * (double)dh.x));
+    const double cc = fma(ocz, ocz, fma(ocy, ocy, fma(ocx, ocx, -w.r2)));
+    const double disc = fma(hb, hb, -cc);              // |dh| = 1
     if (disc < 0.0) return false;
-    double sq = sqrt_f64(disc);
-    double inv_a = rcp_f64(a);
-    double root = (-hb - sq) * inv_a;
-    if (far_only || root < t_min || root > t_max) {
-        root = (-hb + sq) * inv_a;
-        if (root < t_min || root > t_max) return false;
+    const float hbf = (float)hb, ccf = (float)cc;
+    const float sq = __builtin_amdgcn_sqrtf((float)disc);
+    const float q = hbf < 0.0f ? sq - hbf : -hbf - sq;
+    const float other = ccf * __builtin_amdgcn_rcpf(q);   // q = 0 only for a tangent ray from the surface: NaN, no hit
+    const float near = hbf < 0.0f ? other : q, far = hbf < 0.0f ? q : other;
+    float root = near;
+    if (far_only || !(root >= tn_min && root <= tn_max)) {
+        root = far;
+        if (!(root >= tn_min && root <= tn_max)) return false;
     }
-    t_out = root;
+    tn_out = root;
     return true;
 }
 
@@ -267,7 +242,7 @@ __device__ __forceinline__ void leaf_spheres(const G& geo, int first, int count,
 
 __device__ __forceinline__ Cand no_hit() {
     Cand best;
-    best.tn = kInf; best.td = 0.0; best.kind = -1; best.idx = -1; best.obj = -1;
+    best.tn = kInf; best.kind = -1; best.idx = -1; best.obj = -1;
     return best;
 }
 
@@ -298,13 +273,11 @@ __device__ __forceinline__ void hit_always(const DScene& sc, V3 o, V3 d, const R
     const int from_wide = from.wide(), from_rect = from.rect();
     for (int i = 0; i < sc.n_wide; i++) {
         const DWide w = sc.wide[i];
-        double t;
+        float tn;
         if (COUNT) cn.wide++;
         if (i == from_wide && !from.inward()) continue;
-        // only wide spheres have been seen so far: compare in double, later object wins a tie
-        double tmax = best.kind < 0 ? (double)kInf : best.td;
-        if (wide_hit(w, o, d, (double)t_min, tmax, i == from_wide, t) && (best.kind < 0 || t < best.td || w.obj > best.obj)) {
-            best.tn = (float)(t * (double)rn.len); best.td = t; best.kind = 1; best.idx = i; best.obj = w.obj;
+        if (wide_hit(w, o, rn.dh, rn.tn_min, best.tn, i == from_wide, tn) && better(tn, w.obj, best)) {
+            best.tn = tn; best.kind = 1; best.idx = i; best.obj = w.obj;
         }
     }
     for (int i = 0; i < sc.n_rects; i++) {
@@ -320,7 +293,7 @@ __device__ __forceinline__ void hit_always(const DScene& sc, V3 o, V3 d, const R
         }
         if (rect_test(r, q.num, q.o, q.d, t_min, kInf, t)) {
             float tn = t * rn.len;
-            if (better(tn, r.obj, best)) { best.tn = tn; best.td = (double)t; best.kind = 2; best.idx = i; best.obj = r.obj; }
+            if (better(tn, r.obj, best)) { best.tn = tn; best.kind = 2; best.idx = i; best.obj = r.obj; }
         }
     }
 }
@@ -512,7 +485,7 @@ __device__ __forceinline__ Rec make_record(const DScene& sc, const Cand& c, V3 o
     if (c.kind == 2) {
         const DRect q = sc.rects[c.idx];
         int ka = q.axes & 3, aa = (q.axes >> 2) & 3, ba = (q.axes >> 4) & 3;
-        float t = (float)c.td;
+        float t = c.tn * inv_len;
         r.t = t;
         r.p = madd(o, t, d);
         V3 axis = mk(ka == 0 ? 1.0f : 0.0f, ka == 1 ? 1.0f : 0.0f, ka == 2 ? 1.0f : 0.0f);
@@ -536,27 +509,27 @@ __device__ __forceinline__ Rec make_record(const DScene& sc, const Cand& c, V3 o
     }
     double cx, cy, cz, rad, t;
     int xform = 0;
+    const float tf = c.tn * inv_len;
     if (c.kind == 1) {
         const DWide w = sc.wide[c.idx];
-        cx = w.cx; cy = w.cy; cz = w.cz; rad = w.r; t = c.td;
+        cx = w.cx; cy = w.cy; cz = w.cz; rad = w.r;
         r.mat = w.mat;
         xform = w.xform;
     } else {
         if (want_uv && sc.sph_xform) xform = sc.sph_xform[c.idx];
-        float tf = c.tn * inv_len;
         r.mat = mat;
-        if (!refine) {
-            float4 s = sc.sph[c.idx];
-            const float rad32 = (float)s64.w;                    // sph holds |r|
-            r.hollow = rad32 < 0.0f;
-            r.t = tf;
-            r.p = madd(o, tf, d);
-            V3 on = (1.0f / rad32) * mk(r.p.x - s.x, r.p.y - s.y, r.p.z - s.z);
-            face(r, d, on);
-            if (want_uv) sphere_uv_inst(sc, xform, on, r.u, r.v);
-            return r;
-        }
         cx = s64.x; cy = s64.y; cz = s64.z; rad = s64.w;
+    }
+    if (!refine) {
+        r.hollow = rad < 0.0;
+        r.t = tf;
+        r.p = madd(o, tf, d);
+        V3 on = (1.0f / (float)rad) * mk(r.p.x - (float)cx, r.p.y - (float)cy, r.p.z - (float)cz);
+        face(r, d, on);
+        if (want_uv) sphere_uv_inst(sc, xform, on, r.u, r.v);
+        return r;
+    }
+    {
         double ocx = (double)o.x - cx, ocy = (double)o.y - cy, ocz = (double)o.z - cz;
         double dx = d.x, dy = d.y, dz = d.z;
         double a = dx * dx + dy * dy + dz * dz;
