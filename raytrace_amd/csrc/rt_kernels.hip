@@ -15,6 +15,10 @@
 // distance and normal agree with the double-precision reference to float rounding.
 #include "rt_bvh.h"
 #include "rt_device.h"
+
+#ifndef RT_WG_PER_CU
+#define RT_WG_PER_CU 5                 // workgroups of 256 threads per CU = waves per SIMD the render kernel is compiled for
+#endif
 #include "rt_philox.h"
 
 namespace rt {
@@ -815,7 +819,7 @@ __device__ __forceinline__ float from_fixed(unsigned long long q) { return (floa
 // Dynamic LDS: [traversal stack: stack_depth x kBlock ints][accumulators: 4 waves x 3P u64]
 // then, for the LDS-resident variant, [nodes][spheres][list positions].
 template <bool COUNT, bool LDS, bool PROF, bool SLICED>
-__global__ __launch_bounds__(kBlock, 5) void render_kernel(DScene sc, DCamera cam, DRender rp, float4* __restrict__ out,
+__global__ __launch_bounds__(kBlock, RT_WG_PER_CU) void render_kernel(DScene sc, DCamera cam, DRender rp, float4* __restrict__ out,
                                                         unsigned long long* __restrict__ counters) {
     extern __shared__ __align__(16) int s_dyn[];
     int* stack = s_dyn + threadIdx.x;
@@ -1035,7 +1039,7 @@ hipError_t launch_render(const DScene& sc, const DCamera& cam, const DRender& rp
     // persistent waves: enough workgroups to fill 256 CUs at the kernel's occupancy
     // (5 workgroups per CU), never more than there are tiles
     long long blocks = (tiles + (kBlock / 64) - 1) / (kBlock / 64);
-    if (blocks > 256 * 5) blocks = 256 * 5;
+    if (blocks > 256 * RT_WG_PER_CU) blocks = 256 * RT_WG_PER_CU;
     // dynamic LDS: the traversal stack (one entry per BVH level), the per-pixel accumulators and,
     // when it all fits in a budget that still leaves four workgroups per CU, a copy of the BVH
     // and the sphere list

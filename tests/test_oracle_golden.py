@@ -19,7 +19,7 @@ def test_philox_known_answers(oracle):
 
 
 def test_stored_scene_is_the_gxx_scene(rtiow_flat):
-    # SURVEY-level facts about the g++ build of main.cc:37-85
+    # facts about the scene the g++ build of main.cc:37-85 produces
     assert rtiow_flat.n_prims == 487
     counts = np.bincount(rtiow_flat.mat_type, minlength=3)
     assert tuple(counts[:3]) == (394, 64, 29)
