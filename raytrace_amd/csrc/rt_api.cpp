@@ -122,13 +122,17 @@ int shard_rows(int height, int tile_rows, int tile_first, int tile_step) {
 
 int choose_lanes_per_pixel(long long pixels, int spp) {
     // A wave's tile holds 64/K pixels.  K = 4 (an 8x2 tile, four samples of a pixel in flight at
-    // once) measured best on 1080p frames: the lanes' primary rays are more coherent than with
-    // a whole 8x8 tile.  Small frames take a larger K so that there are enough waves to fill
-    // 256 CUs several times over.  Decided from the whole frame (not from a shard); the image
-    // itself does not depend on K (integer accumulation).
-    const long long want_waves = 16384;
+    // once) measured best on whole 1080p frames: the lanes' primary rays are more coherent than
+    // with a whole 8x8 tile.  The persistent grid has 5120 waves and a tile is the unit they
+    // draw; with too few tiles per wave the last tiles of a launch leave most of the chip idle
+    // (one eighth of a 1080p frame at K = 4: 5.1 ms instead of the ideal 3.1; at K = 16: 3.9).
+    // So K grows with the number of tiles the launch (a rank's shard, not the frame) would have;
+    // each doubling costs some coherence, so it asks for less.  Measured on 1/2, 1/4, 1/8 of the
+    // 1080p frame: best K = 8, 8, 16.  The image does not depend on K (integer accumulation).
     int k = spp >= 4 ? 4 : (spp >= 2 ? 2 : 1);
-    while (k < 64 && pixels * k / 64 < want_waves && 2 * k <= spp) k *= 2;
+    if (k == 4 && 2 * k <= spp && pixels * 4 / 64 < 100000) k = 8;
+    if (k == 8 && 2 * k <= spp && pixels * 8 / 64 < 50000) k = 16;
+    while (k < 64 && 2 * k <= spp && pixels * k / 64 < 5120) k *= 2;      // tiny frames: at least a tile per wave
     return k;
 }
 
@@ -148,8 +152,7 @@ int validate_render(rt_context* ctx, const rt_render_params* p, rt::DRender* rp)
     if (!whole && (p->tile_rows < 1 || p->tile_step < 1 || p->tile_first < 0 || p->tile_first >= p->tile_step))
         return fail(ctx, RT_ERR_INVALID, "tiles: tile_rows >= 1, 0 <= tile_first < tile_step required");
     int k = p->lanes_per_pixel;
-    if (k == 0) k = choose_lanes_per_pixel((long long)p->width * p->height, p->spp);
-    if (k < 1 || k > 64 || (k & (k - 1)) != 0)
+    if (k < 0 || k > 64 || (k & (k - 1)) != 0)
         return fail(ctx, RT_ERR_INVALID, "lanes_per_pixel must be 0 or a power of two <= 64");
     if (!(p->t_min >= 0.0f) || !std::isfinite(p->t_min)) return fail(ctx, RT_ERR_INVALID, "t_min must be >= 0");
     rp->width = p->width; rp->height = p->height;
@@ -159,6 +162,7 @@ int validate_render(rt_context* ctx, const rt_render_params* p, rt::DRender* rp)
     rp->tile_first = whole ? 0 : p->tile_first;
     rp->tile_step = whole ? 1 : p->tile_step;
     rp->rows = shard_rows(p->height, rp->tile_rows, rp->tile_first, rp->tile_step);
+    if (k == 0) k = choose_lanes_per_pixel((long long)p->width * rp->rows, p->spp);
     rp->t_min = p->t_min == 0.0f ? 0.001f : p->t_min;
     rp->flags = p->flags;
     rp->lanes_per_pixel = k;
