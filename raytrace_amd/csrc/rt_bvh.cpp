@@ -32,6 +32,7 @@ struct Builder {
     std::vector<float> nodes;
     int max_depth = 44;
     int depth_seen = 0;
+    int64_t sweep_max = 0;           // ranges up to this size are split by the exact sweep, larger ones by bins
     int leaf_max = 4;                // a range of at most this many spheres may become a leaf
     float node_cost = 0.0f;          // cost of visiting an inner node in units of one sphere test; 0: split down to leaf_max
 
@@ -43,6 +44,37 @@ struct Builder {
 
     int32_t leaf_code(int64_t first, int64_t count) const {
         return ~(int32_t)((first << kLeafBits) | (count - 1));
+    }
+
+    // Exact surface-area-heuristic split of order[first, first+count): the range is sorted by
+    // centroid along each axis in turn and every position is priced; the range is left sorted
+    // along the winning axis.  Returns the first index of the right part, or -1.
+    int64_t sweep_split(int64_t first, int64_t count) {
+        float best_cost = std::numeric_limits<float>::infinity();
+        int best_axis = -1;
+        int64_t best_k = -1;
+        std::vector<float> right_area((size_t)count);
+        for (int a = 0; a < 3; a++) {
+            std::sort(order.begin() + first, order.begin() + first + count, [&](int32_t x, int32_t y) {
+                float cx = centroid[3 * (size_t)x + a], cy = centroid[3 * (size_t)y + a];
+                return cx < cy || (cx == cy && x < y);
+            });
+            Box acc; acc.reset();
+            for (int64_t k = count - 1; k > 0; k--) { acc.grow(boxes[order[first + k]]); right_area[(size_t)k] = acc.half_area(); }
+            acc.reset();
+            for (int64_t k = 1; k < count; k++) {
+                acc.grow(boxes[order[first + k - 1]]);
+                float cost = acc.half_area() * (float)k + right_area[(size_t)k] * (float)(count - k);
+                if (cost < best_cost) { best_cost = cost; best_axis = a; best_k = k; }
+            }
+        }
+        if (best_axis < 0) return -1;
+        if (best_axis != 2)
+            std::sort(order.begin() + first, order.begin() + first + count, [&](int32_t x, int32_t y) {
+                float cx = centroid[3 * (size_t)x + best_axis], cy = centroid[3 * (size_t)y + best_axis];
+                return cx < cy || (cx == cy && x < y);
+            });
+        return first + best_k;
     }
 
     // Builds the subtree over order[first, first+count); returns its child code and bounds.
@@ -60,7 +92,11 @@ struct Builder {
             }
 
         int64_t mid = -1;
-        bool balanced = depth + ceil_log2((count + leaf_max - 1) / leaf_max) + 1 >= max_depth;
+        // small ranges: the exact sweep (every split position on every axis) instead of bins
+        if (count <= sweep_max && depth + ceil_log2((count + leaf_max - 1) / leaf_max) + 1 < max_depth) {
+            mid = sweep_split(first, count);
+        }
+        bool balanced = mid > first || depth + ceil_log2((count + leaf_max - 1) / leaf_max) + 1 >= max_depth;   // "balanced": skip the binned search
         if (!balanced) {
             float best_cost = std::numeric_limits<float>::infinity();
             int best_axis = -1, best_bin = -1;
@@ -146,6 +182,8 @@ BvhResult build_bvh(const double* centers, const double* radii, int64_t n, int m
     b.max_depth = max_depth;
     b.leaf_max = leaf_max < 1 ? 1 : (leaf_max > kLeafCap ? kLeafCap : leaf_max);
     b.node_cost = node_cost;
+    // the sweep sorts each range three times: worth it where the build is over in milliseconds
+    b.sweep_max = n <= 65536 ? 4096 : 0;
     b.boxes.resize((size_t)n);
     b.centroid.resize(3 * (size_t)n);
     b.order.resize((size_t)n);
