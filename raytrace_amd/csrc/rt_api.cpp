@@ -169,6 +169,8 @@ int validate_render(rt_context* ctx, const rt_render_params* p, rt::DRender* rp)
     rp->inv_wm1 = (float)(1.0 / (double)(p->width - 1));
     rp->inv_hm1 = (float)(1.0 / (double)(p->height - 1));
     {
+        // RT_TUNE_SLICE (an integer) overrides the traversal time slice for tuning runs
+        // (tools/tune_probe.py); unset in normal use
         const char* v = std::getenv("RT_TUNE_SLICE");
         rp->slice = v && *v ? std::atoi(v) : 0x7fffffff;      // 0x7fffffff: chosen at launch from the tree depth
     }
@@ -388,10 +390,7 @@ int rt_upload_scene(rt_context* ctx, const rt_scene_desc* d) {
     std::vector<int32_t> order((size_t)ns);
     for (int64_t i = 0; i < ns; i++) order[i] = (int32_t)i;
     if (use_bvh && !device_build) {
-        const char* lm = std::getenv("RT_TUNE_LEAF_MAX");
-        const char* nc = std::getenv("RT_TUNE_NODE_COST");
-        bvh = rt::build_bvh(sc_c.data(), sc_r.data(), ns, rt::kMaxStack - 4, lm && *lm ? std::atoi(lm) : 4,
-                            nc && *nc ? (float)std::atof(nc) : 0.0f);
+        bvh = rt::build_bvh(sc_c.data(), sc_r.data(), ns, rt::kMaxStack - 4);
         if (bvh.depth > rt::kMaxStack - 2) return fail(ctx, RT_ERR_UNSUPPORTED, "BVH deeper than the traversal stack");
         order = bvh.order;
     }

@@ -847,121 +847,121 @@ __global__ __launch_bounds__(kBlock, RT_WG_PER_CU) void render_kernel(DScene sc,
     const bool refine = (rp.flags & 2u) == 0u;
     unsigned long long ph[5] = {0, 0, 0, 0, 0}, tq = 0;
 
-  // Persistent waves: the grid is sized to fill the chip once and every wave keeps drawing
-  // tiles from one device-wide counter until none are left, so the geometry is staged once per
-  // workgroup and light (sky) and heavy tiles balance out across the waves.
-  constexpr int kBands = LDS ? 1 : 8;
-  int band = LDS ? 0 : (int)(__builtin_amdgcn_s_getreg(6164) & 7u), bands_tried = 0;   // HW_REG_XCC_ID[3:0]
-  for (;;) {
-    // Tiles are dealt in eight contiguous bands, one per XCD (each XCD has its own L2, so the rays
-    // of one band keep re-using the BVH nodes that XCD has cached); a wave whose band has run
-    // out helps with the next one.
-    // With the geometry in LDS there is nothing to re-use in L2 and one band (bottom rows, the
-    // heaviest, first) leaves the shortest tail.
-    unsigned tile = n_tiles;
-    while (bands_tried < kBands) {
-        const unsigned b0 = (unsigned)(((unsigned long long)n_tiles * band) / kBands), b1 = (unsigned)(((unsigned long long)n_tiles * (band + 1)) / kBands);
-        unsigned t = 0u;
-        if (lane == 0) t = atomicAdd(tile_counter + band, 1u);
-        t = (unsigned)__builtin_amdgcn_readfirstlane((int)t);
-        if (b0 + t < b1) { tile = b0 + t; break; }
-        band = (band + 1) % kBands;
-        bands_tried++;
-    }
-    if (tile >= n_tiles) break;
-    const bool wave_ok = true;
-    const int x0 = (int)(tile % (unsigned)tiles_x) * TW, ly0 = (int)(tile / (unsigned)tiles_x) * TH;
-    if (lane < P) {
-        accum[lane * 3 + 0] = 0ull; accum[lane * 3 + 1] = 0ull; accum[lane * 3 + 2] = 0ull;
-        const int x = x0 + (lane % TW), ly = ly0 + (lane / TW);
-        const int j = (rp.tile_first + (ly / rp.tile_rows) * rp.tile_step) * rp.tile_rows + (ly % rp.tile_rows);
-        tile_pix[lane] = make_int2((x < rp.width && ly < rp.rows && j < rp.height) ? x : -1, j);
-    }
-    __builtin_amdgcn_wave_barrier();                   // LDS serves one wave's accesses in issue order
-
-    const unsigned long long total = (rp.max_depth > 0) ? ((unsigned long long)rp.spp << logP) : 0ull;
-    unsigned long long next = 0ull;                    // wave-uniform: first unit not handed out yet
-    bool has = false;                                  // this lane is on a path
-    int q = 0, depth = 0;                              // pixel of the tile, rays traced on the path
-    Origin from = no_origin();                         // the primitive the ray starts on
-    V3 o = mk(0, 0, 0), d = mk(0, 0, 1), T = mk(1, 1, 1), L = mk(0, 0, 0);
-    // closest-hit query in progress: candidate so far and traversal position.  cur == kTravDone
-    // on a lane with a path means "ray not started yet".
-    Cand c = no_hit();
-    int cur = kTravDone, sp = 0;
+    // Persistent waves: the grid is sized to fill the chip once and every wave keeps drawing
+    // tiles from one device-wide counter until none are left, so the geometry is staged once per
+    // workgroup and light (sky) and heavy tiles balance out across the waves.
+    constexpr int kBands = LDS ? 1 : 8;
+    int band = LDS ? 0 : (int)(__builtin_amdgcn_s_getreg(6164) & 7u), bands_tried = 0;   // HW_REG_XCC_ID[3:0]
     for (;;) {
-        if (PROF) tq = clk();
-        const unsigned long long need = __ballot(!has);
-        if (need != 0ull && next < total) {
-            const unsigned long long u = next + (unsigned long long)__builtin_amdgcn_mbcnt_hi((unsigned)(need >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)need, 0u));
-            if (!has && u < total) {
-                q = (int)(u & (unsigned long long)(P - 1));
-                const int2 xj = tile_pix[q];
-                const int x = xj.x, j = xj.y;
-                if (x >= 0) {
-                    key.pixel = (uint32_t)(j * rp.width + x);
-                    key.sample = (uint32_t)rp.sample_begin + (uint32_t)(u >> logP);
-                    camera_ray(cam, rp, key, x, j, o, d);
-                    T = mk(1.0f, 1.0f, 1.0f);
-                    L = mk(0.0f, 0.0f, 0.0f);
-                    depth = 0;
-                    from = no_origin();
-                    nsamples++;
-                    has = true;
-                }
-            }
-            next += (unsigned long long)__popcll(need);
+        // Tiles are dealt in eight contiguous bands, one per XCD (each XCD has its own L2, so the rays
+        // of one band keep re-using the BVH nodes that XCD has cached); a wave whose band has run
+        // out helps with the next one.
+        // With the geometry in LDS there is nothing to re-use in L2 and one band (bottom rows, the
+        // heaviest, first) leaves the shortest tail.
+        unsigned tile = n_tiles;
+        while (bands_tried < kBands) {
+            const unsigned b0 = (unsigned)(((unsigned long long)n_tiles * band) / kBands), b1 = (unsigned)(((unsigned long long)n_tiles * (band + 1)) / kBands);
+            unsigned t = 0u;
+            if (lane == 0) t = atomicAdd(tile_counter + band, 1u);
+            t = (unsigned)__builtin_amdgcn_readfirstlane((int)t);
+            if (b0 + t < b1) { tile = b0 + t; break; }
+            band = (band + 1) % kBands;
+            bands_tried++;
         }
-        if (PROF) { unsigned long long t = clk(); ph[0] += t - tq; tq = t; }
-        if (__ballot(has) == 0ull) {
-            if (next >= total) break;
-            continue;
+        if (tile >= n_tiles) break;
+        const bool wave_ok = true;
+        const int x0 = (int)(tile % (unsigned)tiles_x) * TW, ly0 = (int)(tile / (unsigned)tiles_x) * TH;
+        if (lane < P) {
+            accum[lane * 3 + 0] = 0ull; accum[lane * 3 + 1] = 0ull; accum[lane * 3 + 2] = 0ull;
+            const int x = x0 + (lane % TW), ly = ly0 + (lane / TW);
+            const int j = (rp.tile_first + (ly / rp.tile_rows) * rp.tile_step) * rp.tile_rows + (ly % rp.tile_rows);
+            tile_pix[lane] = make_int2((x < rp.width && ly < rp.rows && j < rp.height) ? x : -1, j);
         }
-        if (has) {
-            const RayN rn = normalise(d, rp.t_min);
-            // without time slices a query starts and ends inside one trip: its state is local
-            Cand c_trip = no_hit();
-            int cur_trip = kTravDone, sp_trip = 0;
-            Cand& cq = *(SLICED ? &c : &c_trip);
-            int& curq = *(SLICED ? &cur : &cur_trip);
-            int& spq = *(SLICED ? &sp : &sp_trip);
-            if (curq == kTravDone) {                   // a new ray: always-tested primitives first
-                cq = no_hit();
-                hit_always<COUNT>(sc, o, d, rn, rp.t_min, from, cq, cn);
-                nrays++;
-                depth++;
-                if (!sc.use_bvh) hit_list<COUNT>(sc, o, rn, from, cq, cn);
-                else if (sc.root != kNoBvh) { hit_own_sphere(geo, o, rn, from, cq); curq = sc.root; spq = 0; }
-            }
-            if (PROF) { unsigned long long t = clk(); ph[1] += t - tq; tq = t; }
-            if (curq != kTravDone) hit_bvh<COUNT, SLICED>(geo, o, rn, from, stack, rp.slice, curq, spq, cq, cn);
-            if (PROF) { unsigned long long t = clk(); ph[2] += t - tq; tq = t; }
-            if (curq == kTravDone) {                   // query finished (else: resumed next trip)
-                if (shade<COUNT>(sc, geo, rp, cq, key, depth, refine, rn, o, d, T, L, from, cn)) {
-                    atomicAdd(&accum[q * 3 + 0], to_fixed(L.x));
-                    atomicAdd(&accum[q * 3 + 1], to_fixed(L.y));
-                    atomicAdd(&accum[q * 3 + 2], to_fixed(L.z));
-                    has = false;
-                }
-            }
-            if (PROF) { unsigned long long t = clk(); ph[4] += t - tq; tq = t; }
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_wave_barrier();                   // LDS serves one wave's accesses in issue order
 
-    // one float4 store per pixel of the tile
-    if (wave_ok && lane < P) {
-        const int x = x0 + (lane % TW), ly = ly0 + (lane / TW);
-        const int j = (rp.tile_first + (ly / rp.tile_rows) * rp.tile_step) * rp.tile_rows + (ly % rp.tile_rows);
-        if (x < rp.width && ly < rp.rows && j < rp.height) {
-            float a = (float)rp.spp;
-            V3 total_rgb = mk(from_fixed(accum[lane * 3 + 0]), from_fixed(accum[lane * 3 + 1]), from_fixed(accum[lane * 3 + 2]));
-            if (rp.flags & 1u) total_rgb = (1.0f / a) * total_rgb;
-            out[(size_t)ly * rp.width + x] = make_float4(total_rgb.x, total_rgb.y, total_rgb.z, a);
+        const unsigned long long total = (rp.max_depth > 0) ? ((unsigned long long)rp.spp << logP) : 0ull;
+        unsigned long long next = 0ull;                    // wave-uniform: first unit not handed out yet
+        bool has = false;                                  // this lane is on a path
+        int q = 0, depth = 0;                              // pixel of the tile, rays traced on the path
+        Origin from = no_origin();                         // the primitive the ray starts on
+        V3 o = mk(0, 0, 0), d = mk(0, 0, 1), T = mk(1, 1, 1), L = mk(0, 0, 0);
+        // closest-hit query in progress: candidate so far and traversal position.  cur == kTravDone
+        // on a lane with a path means "ray not started yet".
+        Cand c = no_hit();
+        int cur = kTravDone, sp = 0;
+        for (;;) {
+            if (PROF) tq = clk();
+            const unsigned long long need = __ballot(!has);
+            if (need != 0ull && next < total) {
+                const unsigned long long u = next + (unsigned long long)__builtin_amdgcn_mbcnt_hi((unsigned)(need >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)need, 0u));
+                if (!has && u < total) {
+                    q = (int)(u & (unsigned long long)(P - 1));
+                    const int2 xj = tile_pix[q];
+                    const int x = xj.x, j = xj.y;
+                    if (x >= 0) {
+                        key.pixel = (uint32_t)(j * rp.width + x);
+                        key.sample = (uint32_t)rp.sample_begin + (uint32_t)(u >> logP);
+                        camera_ray(cam, rp, key, x, j, o, d);
+                        T = mk(1.0f, 1.0f, 1.0f);
+                        L = mk(0.0f, 0.0f, 0.0f);
+                        depth = 0;
+                        from = no_origin();
+                        nsamples++;
+                        has = true;
+                    }
+                }
+                next += (unsigned long long)__popcll(need);
+            }
+            if (PROF) { unsigned long long t = clk(); ph[0] += t - tq; tq = t; }
+            if (__ballot(has) == 0ull) {
+                if (next >= total) break;
+                continue;
+            }
+            if (has) {
+                const RayN rn = normalise(d, rp.t_min);
+                // without time slices a query starts and ends inside one trip: its state is local
+                Cand c_trip = no_hit();
+                int cur_trip = kTravDone, sp_trip = 0;
+                Cand& cq = *(SLICED ? &c : &c_trip);
+                int& curq = *(SLICED ? &cur : &cur_trip);
+                int& spq = *(SLICED ? &sp : &sp_trip);
+                if (curq == kTravDone) {                   // a new ray: always-tested primitives first
+                    cq = no_hit();
+                    hit_always<COUNT>(sc, o, d, rn, rp.t_min, from, cq, cn);
+                    nrays++;
+                    depth++;
+                    if (!sc.use_bvh) hit_list<COUNT>(sc, o, rn, from, cq, cn);
+                    else if (sc.root != kNoBvh) { hit_own_sphere(geo, o, rn, from, cq); curq = sc.root; spq = 0; }
+                }
+                if (PROF) { unsigned long long t = clk(); ph[1] += t - tq; tq = t; }
+                if (curq != kTravDone) hit_bvh<COUNT, SLICED>(geo, o, rn, from, stack, rp.slice, curq, spq, cq, cn);
+                if (PROF) { unsigned long long t = clk(); ph[2] += t - tq; tq = t; }
+                if (curq == kTravDone) {                   // query finished (else: resumed next trip)
+                    if (shade<COUNT>(sc, geo, rp, cq, key, depth, refine, rn, o, d, T, L, from, cn)) {
+                        atomicAdd(&accum[q * 3 + 0], to_fixed(L.x));
+                        atomicAdd(&accum[q * 3 + 1], to_fixed(L.y));
+                        atomicAdd(&accum[q * 3 + 2], to_fixed(L.z));
+                        has = false;
+                    }
+                }
+                if (PROF) { unsigned long long t = clk(); ph[4] += t - tq; tq = t; }
+            }
         }
-    }
-    __builtin_amdgcn_wave_barrier();
-  }  // next tile
+        __builtin_amdgcn_wave_barrier();
+
+        // one float4 store per pixel of the tile
+        if (wave_ok && lane < P) {
+            const int x = x0 + (lane % TW), ly = ly0 + (lane / TW);
+            const int j = (rp.tile_first + (ly / rp.tile_rows) * rp.tile_step) * rp.tile_rows + (ly % rp.tile_rows);
+            if (x < rp.width && ly < rp.rows && j < rp.height) {
+                float a = (float)rp.spp;
+                V3 total_rgb = mk(from_fixed(accum[lane * 3 + 0]), from_fixed(accum[lane * 3 + 1]), from_fixed(accum[lane * 3 + 2]));
+                if (rp.flags & 1u) total_rgb = (1.0f / a) * total_rgb;
+                out[(size_t)ly * rp.width + x] = make_float4(total_rgb.x, total_rgb.y, total_rgb.z, a);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }  // next tile
 
     unsigned long long r_all = wave_sum(nrays), s_all = wave_sum(nsamples);
     if (lane == 0 && r_all) {
