@@ -63,7 +63,7 @@ def test_device_bvh_closest_hits_equal_the_scan(api, S, oracle):
     for other in (api.RT_ACCEL_BVH, api.RT_ACCEL_LIST):           # same float arithmetic: identical records
         for f in ("id", "t", "p", "n", "front_face"):
             assert np.array_equal(dev[f], got[other][f]), (other, f)
-    assert (want["id"] >= 0).mean() > 0.3
+    assert (want["id"] >= 0).mean() > 0.2
 
 
 def test_images_do_not_depend_on_the_builder(api, S, rtiow_flat):
@@ -139,3 +139,36 @@ def test_device_bvh_with_instances_and_textures(api, S, oracle):
     assert m.sum() > 500
     assert np.abs(np.stack([h["u"][m], h["v"][m]], 1) - want["uv"][m]).max() <= 2e-5
     ctx.close()
+
+
+def test_auto_uses_the_gpu_builder_for_large_scenes(api, S, oracle):
+    """RT_ACCEL_AUTO hands scenes of 65 536 spheres or more to the GPU builder; the hits are
+    still the linear scan's (checked against the double-precision scan on a sample of rays and
+    against the device's own scan on all of them)."""
+    n = 70000
+    rng = np.random.default_rng(31)
+    c = np.stack([rng.uniform(-200, 200, n), rng.uniform(0, 20, n), rng.uniform(-200, 200, n)], 1)
+    flat = S.FlatScene(
+        prim_type=np.zeros(n, np.int32), prim_geom=np.concatenate([c, rng.uniform(0.2, 0.8, (n, 1)), np.zeros((n, 2))], 1),
+        prim_mat=np.zeros(n, np.int32), mat_type=np.array([S.RT_LAMBERTIAN], np.int32),
+        mat_param=np.array([[0.5, 0.5, 0.5, 0, 0]], np.float64), mat_tex=np.array([-1], np.int32),
+        tex_type=np.zeros(0, np.int32), tex_color=np.zeros((0, 3)), tex_a=np.zeros(0, np.int32), tex_b=np.zeros(0, np.int32),
+        tex_off=np.zeros(0, np.int64), texels=np.zeros(0, np.uint8))
+    rays = _f32(np.concatenate([np.tile([0, 60, -300], (4000, 1)) + rng.normal(size=(4000, 3)),
+                                _unit(np.tile([0, -0.25, 1], (4000, 1)) + 0.2 * rng.normal(size=(4000, 3)))], 1))
+    got = {}
+    for accel in (api.RT_ACCEL_AUTO, api.RT_ACCEL_LIST):
+        ctx = api.Context(0)
+        ctx.upload_scene(flat, accel=accel)
+        got[accel] = ctx.trace_primary(rays)
+        if accel == api.RT_ACCEL_AUTO:
+            ctx.set_camera((0, 60, -300), (0, 5, 0), (0, 1, 0), 40.0, 1.5, 0.0, 10.0)
+            ctx.render_host(api.Context.params(64, 48, 2, 8, 5))
+            st = ctx.stats()
+            assert st["accel"] == api.RT_ACCEL_BVH and st["bvh_nodes"] > 10000 and st["build_ms"] < 200
+        ctx.close()
+    for f in ("id", "t", "p", "n", "front_face"):
+        assert np.array_equal(got[api.RT_ACCEL_AUTO][f], got[api.RT_ACCEL_LIST][f]), f
+    want = oracle.trace(flat, rays[:600])
+    assert (got[api.RT_ACCEL_AUTO]["id"][:600] != want["id"]).sum() <= 1
+    assert (want["id"] >= 0).mean() > 0.2
