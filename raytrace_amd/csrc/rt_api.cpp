@@ -395,7 +395,8 @@ int rt_upload_scene(rt_context* ctx, const rt_scene_desc* d) {
         order = bvh.order;
     }
     // sphere arrays in leaf order (input order when the GPU builder will permute them)
-    const int64_t ns_pad = (ns + 3) / 4 * 4;
+    // a multiple of four (the linear scan's group size) plus four (a leaf is read as four records)
+    const int64_t ns_pad = (ns + 3) / 4 * 4 + 4;
     std::vector<float4> sph((size_t)ns_pad, make_float4(1e30f, 1e30f, 1e30f, 0.0f));
     std::vector<double4> sph64((size_t)ns_pad, make_double4(1e30, 1e30, 1e30, 1.0));
     std::vector<int2> info((size_t)ns_pad, make_int2(-1, 0));

@@ -213,6 +213,7 @@ __device__ __forceinline__ SlabRay slab_ray(V3 o, V3 dh) {
 // Where the traversal reads its geometry from: HBM (through L1/L2), or a copy in LDS that the
 // workgroup makes at kernel start when the whole BVH and sphere list fit.
 struct GeoGlobal {
+    static constexpr bool kPrefetchLeaf = true;
     const float4* nodes; const float4* sph; const int2* info;
     __device__ __forceinline__ float4 node(int i, int q) const { return nodes[4 * (size_t)i + q]; }
     __device__ __forceinline__ float4 sphere(int i) const { return sph[i]; }
@@ -220,6 +221,7 @@ struct GeoGlobal {
     __device__ __forceinline__ int mat(int i) const { return info[i].y; }
 };
 struct GeoLds {
+    static constexpr bool kPrefetchLeaf = false;
     const float4* nodes; const float4* sph; const int* objs;     // all three point into LDS
     __device__ __forceinline__ float4 node(int i, int q) const { return nodes[4 * i + q]; }
     __device__ __forceinline__ float4 sphere(int i) const { return sph[i]; }
@@ -229,18 +231,32 @@ struct GeoLds {
 };
 
 template <bool COUNT, class G>
+__device__ __forceinline__ void leaf_sphere(const G& geo, int i, float4 s, V3 o, V3 dh, float tn_min, int self, Cand& best, Counters& cn) {
+    float tn;
+    if (COUNT) cn.sph++;
+    const float lo = i == self ? kInf : tn_min;        // the sphere the ray starts on is settled before the traversal
+    if (sphere_test(s, o, dh, lo, lo, best.tn, tn)) {
+        int obj = geo.obj(i);
+        if (COUNT) cn.sph_hit++;
+        if (better(tn, obj, best)) { best.tn = tn; best.kind = 0; best.idx = i; best.obj = obj; }
+    }
+}
+
+template <bool COUNT, class G>
 __device__ __forceinline__ void leaf_spheres(const G& geo, int first, int count, V3 o, V3 dh,
                                              float tn_min, int self, Cand& best, Counters& cn) {
-    for (int i = first; i < first + count; i++) {
-        float4 s = geo.sphere(i);
-        float tn;
-        if (COUNT) cn.sph++;
-        const float lo = i == self ? kInf : tn_min;    // the sphere the ray starts on is settled before the traversal
-        if (sphere_test(s, o, dh, lo, lo, best.tn, tn)) {
-            int obj = geo.obj(i);
-            if (COUNT) cn.sph_hit++;
-            if (better(tn, obj, best)) { best.tn = tn; best.kind = 0; best.idx = i; best.obj = obj; }
-        }
+    if constexpr (G::kPrefetchLeaf) {
+        // geometry in HBM: the leaf's (up to) four records are requested together, so that a leaf
+        // costs one memory round trip, not one per sphere (the arrays are padded for the reads
+        // past a shorter leaf)
+        float4 s0 = geo.sphere(first), s1 = geo.sphere(first + 1), s2 = geo.sphere(first + 2), s3 = geo.sphere(first + 3);
+        leaf_sphere<COUNT>(geo, first, s0, o, dh, tn_min, self, best, cn);
+        if (count > 1) leaf_sphere<COUNT>(geo, first + 1, s1, o, dh, tn_min, self, best, cn);
+        if (count > 2) leaf_sphere<COUNT>(geo, first + 2, s2, o, dh, tn_min, self, best, cn);
+        if (count > 3) leaf_sphere<COUNT>(geo, first + 3, s3, o, dh, tn_min, self, best, cn);
+        for (int i = first + 4; i < first + count; i++) leaf_sphere<COUNT>(geo, i, geo.sphere(i), o, dh, tn_min, self, best, cn);
+    } else {
+        for (int i = first; i < first + count; i++) leaf_sphere<COUNT>(geo, i, geo.sphere(i), o, dh, tn_min, self, best, cn);
     }
 }
 
