@@ -18,6 +18,6 @@ def bench(label, ctx, W, H, spp, slices):
 aspect = float(np.float32(16 / 9))
 c = api.Context(0)
 c.upload_scene(S.flatten(S.rtiow_scene())); c.set_camera(**S.rtiow_camera(aspect).desc())
-bench("C2", c, 1920, 1080, 50, [0, 8, 16, 32])
+bench("C2", c, 1920, 1080, 50, [0, 16, 32, 64])
 c.upload_scene(S.stress_flat(1000000), accel=api.RT_ACCEL_BVH); c.set_camera(**S.stress_camera(aspect).desc())
 bench("C4", c, 3840, 2160, 8, [0, 16, 32, 64])
