@@ -99,10 +99,9 @@ __device__ __forceinline__ bool sphere_test(float4 s, V3 o, V3 dh, float lo_near
     V3 L = mk(s.x - o.x, s.y - o.y, s.z - o.z);
     float tca = dot(L, dh);
     V3 l = madd(L, -tca, dh);
-    float l2 = dot(l, l);
-    float r2 = s.w * s.w;
-    if (!(l2 <= r2)) return false;
-    float thc = __builtin_amdgcn_sqrtf(r2 - l2);    // 1 ulp; the winner's root is polished in double
+    float gap = fmaf(s.w, s.w, -dot(l, l));         // r^2 - (distance of the centre from the line)^2, as in hit_list
+    if (!(gap >= 0.0f)) return false;
+    float thc = __builtin_amdgcn_sqrtf(gap);        // 1 ulp; the winner's root is polished in double
     float root = tca - thc;
     if (!(root >= lo_near && root <= tn_max)) {
         root = tca + thc;
