@@ -73,3 +73,28 @@ def test_stratified_sample_of_the_frame_agrees_with_the_checker(frames, oracle, 
     rmse = np.sqrt(np.mean((got - want) ** 2))
     assert rmse <= 1e-3, rmse
     assert (np.abs(got - want).max(axis=2) > 1e-5).mean() < 0.02
+
+
+def test_million_sphere_frame_does_not_depend_on_the_builder(api):
+    """The 10^6-sphere configuration at its full 3840x2160 size (2 samples per pixel here): the
+    host-built and the GPU-built tree give the same bits, and a sample of primary rays hits what
+    the device's own linear scan over all 10^6 spheres hits."""
+    from raytrace_amd import scene as S
+    flat = S.stress_flat(1_000_000)
+    cam = S.stress_camera(float(np.float32(3840 / 2160))).desc()
+    imgs, hits = [], []
+    rng = np.random.default_rng(3)
+    rays = np.concatenate([np.tile([0, 60, -120], (512, 1)), np.tile([0, -0.45, 1], (512, 1)) + 0.3 * rng.normal(size=(512, 3))], 1).astype(np.float32)
+    for accel in (api.RT_ACCEL_BVH, api.RT_ACCEL_BVH_DEVICE, api.RT_ACCEL_LIST):
+        c = api.Context(0)
+        c.upload_scene(flat, accel=accel)
+        c.set_camera(**cam)
+        if accel != api.RT_ACCEL_LIST:
+            imgs.append(c.render_host(api.Context.params(3840, 2160, 2, 50, 1)))
+            assert c.stats()["bvh_depth"] <= 46
+        hits.append(c.trace_primary(rays))
+        c.close()
+    assert np.array_equal(imgs[0], imgs[1]) and imgs[0][..., :3].max() > 0
+    for f in ("id", "t", "front_face"):
+        assert np.array_equal(hits[0][f], hits[2][f]) and np.array_equal(hits[1][f], hits[2][f]), f
+    assert (hits[2]["id"] >= 0).mean() > 0.5
