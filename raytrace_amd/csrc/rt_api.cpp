@@ -144,6 +144,8 @@ int validate_render(rt_context* ctx, const rt_render_params* p, rt::DRender* rp)
     if (!ctx->has_camera) return fail(ctx, RT_ERR_NO_CAMERA, "no camera set");
     if (p->width < 2 || p->height < 2 || p->width > 65536 || p->height > 65536)
         return fail(ctx, RT_ERR_INVALID, "width/height must be in [2, 65536]");
+    if ((long long)p->width * p->height > 0x7fffffffLL)
+        return fail(ctx, RT_ERR_UNSUPPORTED, "more than 2^31 - 1 pixels (the random stream is keyed by a 32-bit pixel index)");
     if (p->spp < 1 || p->sample_begin < 0 || p->max_depth < 0)
         return fail(ctx, RT_ERR_INVALID, "spp >= 1, sample_begin >= 0, max_depth >= 0 required");
     if ((long long)p->sample_begin + p->spp > 0x7fffffffLL)

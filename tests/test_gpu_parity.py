@@ -134,6 +134,9 @@ def test_error_codes(api, rtiow_flat):
     with pytest.raises(api.RtError) as e:
         c.render_host(api.Context.params(64, 48, 1, lanes_per_pixel=3))
     assert e.value.code == api.RT_ERR_INVALID
+    import ctypes
+    dummy = np.zeros(4, np.float32)                      # rejected before anything is written
+    assert api.lib().rt_render_host(c._h, ctypes.byref(api.Context.params(65536, 65536, 1)), dummy.ctypes.data) == api.RT_ERR_UNSUPPORTED
     with pytest.raises(api.RtError):
         c.set_camera((0, 0, 0), (0, 0, 0), (0, 1, 0), 20, 1.5, 0, 10)
     c.close()
