@@ -338,6 +338,7 @@ int rt_upload_scene(rt_context* ctx, const rt_scene_desc* d) {
     bool any_sphere_xf = false;
     std::vector<rt::DWide> wide;
     std::vector<rt::DRect> rects;
+    std::vector<double> rect_k;
     for (int i = 0; i < d->n_prims; i++) {
         const double* g = d->prim_geom + 6 * (size_t)i;
         int mat = d->prim_mat[i];
@@ -373,9 +374,11 @@ int rt_upload_scene(rt_context* ctx, const rt_scene_desc* d) {
             int ka = type == RT_XY_RECT ? 2 : (type == RT_XZ_RECT ? 1 : 0);
             int aa = type == RT_YZ_RECT ? 1 : 0;
             int ba = type == RT_XY_RECT ? 1 : 2;
-            r.axes = ka | (aa << 2) | (ba << 4) | ((xf + 1) << 8);
+            const int k_inexact = (double)r.k != g[4] ? 1 : 0;     // the plane coordinate does not fit a float
+            r.axes = ka | (aa << 2) | (ba << 4) | (k_inexact << 6) | ((xf + 1) << 8);
             r.obj = i; r.mat = mat;
             rects.push_back(r);
+            rect_k.push_back(g[4]);
         } else {
             return fail(ctx, RT_ERR_INVALID, "unknown primitive type");
         }
@@ -421,7 +424,7 @@ int rt_upload_scene(rt_context* ctx, const rt_scene_desc* d) {
     std::vector<uint8_t> texels;
     if (d->texel_bytes && d->texels) texels.assign(d->texels, d->texels + d->texel_bytes);
     if ((rc = upload(ctx, sph, &s.sph)) || (rc = upload(ctx, sph64, &s.sph64)) || (rc = upload(ctx, info, &s.sph_info)) ||
-        (rc = upload(ctx, nodes4, &s.nodes)) || (rc = upload(ctx, wide, &s.wide)) || (rc = upload(ctx, rects, &s.rects)) ||
+        (rc = upload(ctx, nodes4, &s.nodes)) || (rc = upload(ctx, wide, &s.wide)) || (rc = upload(ctx, rects, &s.rects)) || (rc = upload(ctx, rect_k, &s.rect_k)) ||
         (rc = upload(ctx, xforms, &s.xforms)) || (rc = upload(ctx, sph_xf, &s.sph_xform)) ||
         (rc = upload(ctx, mats, &s.mats)) || (rc = upload(ctx, texs, &s.texs)) || (rc = upload(ctx, texels, &s.texels))) {
         std::string keep = ctx->error;
@@ -459,7 +462,7 @@ int rt_upload_scene(rt_context* ctx, const rt_scene_desc* d) {
     }
     ctx->build_ms = use_bvh ? std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_build).count() : 0.0f;
     s.n_sph = (int)ns;
-    s.n_sph_padded = (int)ns_pad;
+    s.n_sph_padded = (int)((ns + 3) / 4 * 4);      // what the linear scan walks; the arrays hold four records more
     s.n_nodes = n_nodes;
     s.root = root;
     s.bvh_depth = depth;

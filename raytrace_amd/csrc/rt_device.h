@@ -35,7 +35,7 @@ struct DXform {
 struct DRect {            // cuda/rect.h: plane axis `ka` at k, in-plane axes (aa, ba)
     float a0, a1, b0, b1;
     float k;
-    int axes;             // ka | aa << 2 | ba << 4 | (1 + instance transform, or 0) << 8
+    int axes;             // ka | aa << 2 | ba << 4 | (k does not fit a float) << 6 | (1 + instance transform, or 0) << 8
     int obj, mat;
 };
 
@@ -62,7 +62,8 @@ struct DScene {
     const double4* sph64;
     const int2* sph_info;
     int n_sph;
-    int n_sph_padded;     // sph / sph_info hold this many records (multiple of 4; the padding cannot be hit)
+    int n_sph_padded;     // n_sph rounded up to a multiple of 4: the linear scan's extent (the padding cannot be hit);
+                          // the arrays hold four more records, for leaves that are read four at a time
     const float4* nodes;
     int n_nodes;
     int root;             // inner index, leaf code, or kNoBvh
@@ -72,6 +73,8 @@ struct DScene {
     const DWide* wide;
     int n_wide;
     const DRect* rects;
+    const double* rect_k; // per rect, the plane coordinate as given (read where the float one does not do:
+                          // instances, and planes that do not fit a float)
     int n_rects;
     const DXform* xforms;
     const int* sph_xform; // per ordinary sphere (leaf order): 0 or 1 + transform; null when no sphere has one

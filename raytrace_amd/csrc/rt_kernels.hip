@@ -136,14 +136,14 @@ __device__ __forceinline__ Origin no_origin() { Origin g; g.code = -1; return g;
 // coordinate k along axis ka, formed before rounding.  cuda/sceneobject.h:98-102: an
 // object-space direction back in the world.
 struct ObjRay { V3 o, d; float num; };
-__device__ __forceinline__ ObjRay to_object(const DXform& x, V3 o, V3 d, int ka, float k) {
+__device__ __forceinline__ ObjRay to_object(const DXform& x, V3 o, V3 d, int ka, double k) {
     double qx = (double)o.x - x.tx, qy = (double)o.y - x.ty, qz = (double)o.z - x.tz;
     double ox = fma(x.c, qx, -x.s * qz), oz = fma(x.s, qx, x.c * qz);
     double dx = fma(x.c, (double)d.x, -x.s * (double)d.z), dz = fma(x.s, (double)d.x, x.c * (double)d.z);
     ObjRay r;
     r.o = mk((float)ox, (float)qy, (float)oz);
     r.d = mk((float)dx, d.y, (float)dz);
-    r.num = (float)((double)k - (ka == 0 ? ox : (ka == 1 ? qy : oz)));
+    r.num = (float)(k - (ka == 0 ? ox : (ka == 1 ? qy : oz)));
     return r;
 }
 __device__ __forceinline__ V3 to_object_dir(const DXform& x, V3 v) {
@@ -286,7 +286,9 @@ __device__ __forceinline__ RayN normalise(V3 d, float t_min) {
 
 // Always-tested primitives: wide spheres (double) and rects.  They run first and tighten the
 // distance bound the BVH traversal prunes with.
-template <bool COUNT>
+// RECTS = false compiles the rect code out (kernels for scenes of spheres only: the rect code is
+// never run there, but its registers and size slowed the sphere path by 3 %).
+template <bool COUNT, bool RECTS>
 __device__ __forceinline__ void hit_always(const DScene& sc, V3 o, V3 d, const RayN& rn, float t_min, Origin from,
                                            Cand& best, Counters& cn) {
     const int from_wide = from.wide(), from_rect = from.rect();
@@ -299,6 +301,7 @@ __device__ __forceinline__ void hit_always(const DScene& sc, V3 o, V3 d, const R
             best.tn = tn; best.kind = 1; best.idx = i; best.obj = w.obj;
         }
     }
+    if constexpr (RECTS)
     for (int i = 0; i < sc.n_rects; i++) {
         const DRect r = sc.rects[i];
         float t;
@@ -306,9 +309,12 @@ __device__ __forceinline__ void hit_always(const DScene& sc, V3 o, V3 d, const R
         if (i == from_rect) continue;
         ObjRay q;
         if (r.axes >> 8) {                   // instance: a rotation keeps |d|, so t means the same
-            q = to_object(sc.xforms[(r.axes >> 8) - 1], o, d, r.axes & 3, r.k);
+            q = to_object(sc.xforms[(r.axes >> 8) - 1], o, d, r.axes & 3, sc.rect_k[i]);
         } else {
-            q.o = o; q.d = d; q.num = r.k - comp(o, r.axes & 3);
+            // the distance to the plane: in float when the plane coordinate is a float (the
+            // subtraction is then as good as the double one rounded), else in double
+            q.o = o; q.d = d;
+            q.num = (r.axes & 64) ? (float)(sc.rect_k[i] - (double)comp(o, r.axes & 3)) : r.k - comp(o, r.axes & 3);
         }
         if (rect_test(r, q.num, q.o, q.d, t_min, kInf, t)) {
             float tn = t * rn.len;
@@ -452,7 +458,7 @@ template <bool COUNT>
 __device__ __forceinline__ Cand closest_hit(const DScene& sc, V3 o, V3 d, float t_min, int* stack, Counters& cn) {
     Cand best = no_hit();
     RayN rn = normalise(d, t_min);
-    hit_always<COUNT>(sc, o, d, rn, t_min, no_origin(), best, cn);
+    hit_always<COUNT, true>(sc, o, d, rn, t_min, no_origin(), best, cn);
     GeoGlobal geo = {sc.nodes, sc.sph, sc.sph_info};
     if (!sc.use_bvh) hit_list<COUNT>(sc, o, rn, no_origin(), best, cn);
     else if (sc.root != kNoBvh) {
@@ -498,13 +504,14 @@ __device__ __forceinline__ void face(Rec& r, V3 d, V3 outward) {
 // f(t) = a t^2 + 2 hb t + c in double from the single-precision root (the correction itself is
 // a float division), then p and the normal from the polished t.
 // `s64` is the winning ordinary sphere in double and `mat` its material, both loaded by the caller.
+template <bool RECTS>
 __device__ __forceinline__ Rec make_record(const DScene& sc, const Cand& c, V3 o, V3 d, float inv_len, bool refine, bool want_uv,
                                            double4 s64, int mat) {
     Rec r;
     r.obj = c.obj;
     r.u = 0.0f; r.v = 0.0f;
     r.hollow = false;
-    if (c.kind == 2) {
+    if (RECTS && c.kind == 2) {
         const DRect q = sc.rects[c.idx];
         int ka = q.axes & 3, aa = (q.axes >> 2) & 3, ba = (q.axes >> 4) & 3;
         float t = c.tn * inv_len;
@@ -517,7 +524,7 @@ __device__ __forceinline__ Rec make_record(const DScene& sc, const Cand& c, V3 o
             // of the surface is the one the instance saw (cuda/sceneobject.h:105 asks again with
             // the object-space ray against the world-space normal, which mixes the two frames).
             const DXform x = sc.xforms[(q.axes >> 8) - 1];
-            ObjRay oq = to_object(x, o, d, ka, q.k);
+            ObjRay oq = to_object(x, o, d, ka, sc.rect_k[c.idx]);
             po = madd(oq.o, t, oq.d);
             face(r, oq.d, axis);
             r.n = to_world_dir(x, r.n);
@@ -558,14 +565,18 @@ __device__ __forceinline__ Rec make_record(const DScene& sc, const Cand& c, V3 o
         double hb = ocx * dx + ocy * dy + ocz * dz;
         double cc = (ocx * ocx + ocy * ocy + ocz * ocz) - rad * rad;
         t = (double)tf;
-        for (int it = 0; it < 2; it++) {
+        const float af = (float)a;
+        for (int it = 0; it < 4; it++) {
             double g = fma(a, t, hb);                 // f'(t) / 2
             double f = fma(g + hb, t, cc);            // (a t + 2 hb) t + c
             float fp = 2.0f * (float)g;
             if (fp == 0.0f) break;
-            float corr = (float)f * __builtin_amdgcn_rcpf(fp);
+            float inv_fp = __builtin_amdgcn_rcpf(fp);
+            float corr = (float)f * inv_fp;
             t -= (double)corr;
-            if (fabsf(corr) <= 1e-5f * fabsf(tf)) break;
+            // a step leaves corr^2 f'' / (2 f') behind.  Nearly always the first step ends it; a
+            // ray that grazes (f' small, and a poorer float estimate to start from) takes more
+            if (corr * corr * fabsf(af * inv_fp) <= 3e-8f * fabsf(tf)) break;
         }
     }
     r.hollow = rad < 0.0;
@@ -762,7 +773,7 @@ __device__ __forceinline__ unsigned long long clk() { return __builtin_amdgcn_s_
 
 // Shade one finished closest-hit query: returns true when the path ended (sample complete).
 // L collects the path's radiance: emitted light along the way and the background at the end.
-template <bool COUNT, class G>
+template <bool COUNT, bool RECTS, class G>
 __device__ __forceinline__ bool shade(const DScene& sc, const G& geo, const DRender& rp, const Cand& c, const Key& key, int depth,
                                       bool refine, const RayN& rn, V3& o, V3& d, V3& T, V3& L, Origin& from, Counters& cn) {
     if (c.kind < 0) {
@@ -771,12 +782,12 @@ __device__ __forceinline__ bool shade(const DScene& sc, const G& geo, const DRen
     }
     // the loads the record and the material need go out first; the Philox block below is pure
     // arithmetic and runs while they are in flight
-    const int mat = c.kind == 0 ? geo.mat(c.idx) : (c.kind == 1 ? sc.wide[c.idx].mat : sc.rects[c.idx].mat);
+    const int mat = c.kind == 0 ? geo.mat(c.idx) : ((!RECTS || c.kind == 1) ? sc.wide[c.idx].mat : sc.rects[c.idx].mat);
     const double4 s64 = c.kind == 0 ? sc.sph64[c.idx] : make_double4(0.0, 0.0, 0.0, 1.0);
     const DMaterial m = sc.mats[mat];
     // one Philox block per scatter segment, shared by whichever material consumes it
     const uint4 w = philox4x32_10(key.pixel, key.sample, (uint32_t)depth, 0u, key.seed_lo, key.seed_hi);
-    Rec r = make_record(sc, c, o, d, rn.inv_len, refine, m.tex >= 0, s64, mat);
+    Rec r = make_record<RECTS>(sc, c, o, d, rn.inv_len, refine, m.tex >= 0, s64, mat);
     V3 att, sd, em;
     if (COUNT) cn.shade++;
     V3 rs = mk(0.0f, 0.0f, 0.0f);
@@ -836,7 +847,7 @@ __device__ __forceinline__ float from_fixed(unsigned long long q) { return (floa
 // one ray on all 64 lanes until the tile runs out of samples, whatever the path lengths were.
 // Dynamic LDS: [traversal stack: stack_depth x kBlock ints][accumulators: 4 waves x 3P u64]
 // then, for the LDS-resident variant, [nodes][spheres][list positions].
-template <bool COUNT, bool LDS, bool PROF, bool SLICED>
+template <bool COUNT, bool LDS, bool PROF, bool SLICED, bool RECTS>
 __global__ __launch_bounds__(kBlock, RT_WG_PER_CU) void render_kernel(DScene sc, DCamera cam, DRender rp, float4* __restrict__ out,
                                                         unsigned long long* __restrict__ counters) {
     extern __shared__ __align__(16) int s_dyn[];
@@ -945,7 +956,7 @@ __global__ __launch_bounds__(kBlock, RT_WG_PER_CU) void render_kernel(DScene sc,
                 int& spq = *(SLICED ? &sp : &sp_trip);
                 if (curq == kTravDone) {                   // a new ray: always-tested primitives first
                     cq = no_hit();
-                    hit_always<COUNT>(sc, o, d, rn, rp.t_min, from, cq, cn);
+                    hit_always<COUNT, RECTS>(sc, o, d, rn, rp.t_min, from, cq, cn);
                     nrays++;
                     depth++;
                     if (!sc.use_bvh) hit_list<COUNT>(sc, o, rn, from, cq, cn);
@@ -955,7 +966,7 @@ __global__ __launch_bounds__(kBlock, RT_WG_PER_CU) void render_kernel(DScene sc,
                 if (curq != kTravDone) hit_bvh<COUNT, SLICED>(geo, o, rn, from, stack, rp.slice, curq, spq, cq, cn);
                 if (PROF) { unsigned long long t = clk(); ph[2] += t - tq; tq = t; }
                 if (curq == kTravDone) {                   // query finished (else: resumed next trip)
-                    if (shade<COUNT>(sc, geo, rp, cq, key, depth, refine, rn, o, d, T, L, from, cn)) {
+                    if (shade<COUNT, RECTS>(sc, geo, rp, cq, key, depth, refine, rn, o, d, T, L, from, cn)) {
                         atomicAdd(&accum[q * 3 + 0], to_fixed(L.x));
                         atomicAdd(&accum[q * 3 + 1], to_fixed(L.y));
                         atomicAdd(&accum[q * 3 + 2], to_fixed(L.z));
@@ -1017,7 +1028,7 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(DScene sc, const float* _
         for (int a = 0; a < 3; a++) { h.p[a] = 0.0f; h.n[a] = 0.0f; }
     } else {
         const double4 s64 = c.kind == 0 ? sc.sph64[c.idx] : make_double4(0.0, 0.0, 0.0, 1.0);
-        Rec r = make_record(sc, c, o, d, normalise(d, t_min).inv_len, (flags & 2u) == 0u, true, s64, c.kind == 0 ? sc.sph_info[c.idx].y : 0);
+        Rec r = make_record<true>(sc, c, o, d, normalise(d, t_min).inv_len, (flags & 2u) == 0u, true, s64, c.kind == 0 ? sc.sph_info[c.idx].y : 0);
         h.id = r.obj; h.t = r.t; h.front = r.front; h.u = r.u; h.v = r.v;
         h.p[0] = r.p.x; h.p[1] = r.p.y; h.p[2] = r.p.z;
         h.n[0] = r.n.x; h.n[1] = r.n.y; h.n[2] = r.n.z;
@@ -1075,11 +1086,13 @@ hipError_t launch_render(const DScene& sc, const DCamera& cam, const DRender& rp
     if (r.slice == 0x7fffffff) r.slice = sc.bvh_depth > 12 ? 32 : 0;
     const bool sliced = sc.use_bvh && r.slice > 0;
 #define RT_LAUNCH(...) hipLaunchKernelGGL((render_kernel<__VA_ARGS__>), grid, block, lds, stream, sc, cam, r, out, counters)
-#define RT_LAUNCH_S(C, L, P) do { if (sliced) RT_LAUNCH(C, L, P, true); else RT_LAUNCH(C, L, P, false); } while (0)
+#define RT_LAUNCH_R(C, L, P, S) do { if (sc.n_rects > 0) RT_LAUNCH(C, L, P, S, true); else RT_LAUNCH(C, L, P, S, false); } while (0)
+#define RT_LAUNCH_S(C, L, P) do { if (sliced) RT_LAUNCH_R(C, L, P, true); else RT_LAUNCH_R(C, L, P, false); } while (0)
     if (prof) { if (in_lds) RT_LAUNCH_S(false, true, true); else RT_LAUNCH_S(false, false, true); }
     else if (count) { if (in_lds) RT_LAUNCH_S(true, true, false); else RT_LAUNCH_S(true, false, false); }
     else { if (in_lds) RT_LAUNCH_S(false, true, false); else RT_LAUNCH_S(false, false, false); }
 #undef RT_LAUNCH_S
+#undef RT_LAUNCH_R
 #undef RT_LAUNCH
     return hipGetLastError();
 }
