@@ -847,9 +847,13 @@ __device__ __forceinline__ float from_fixed(unsigned long long q) { return (floa
 // one ray on all 64 lanes until the tile runs out of samples, whatever the path lengths were.
 // Dynamic LDS: [traversal stack: stack_depth x kBlock ints][accumulators: 4 waves x 3P u64]
 // then, for the LDS-resident variant, [nodes][spheres][list positions].
-template <bool COUNT, bool LDS, bool PROF, bool SLICED, bool RECTS>
+// MODE: 0 linear scan, 1 BVH, 2 BVH walked in time slices.  Each combination is a kernel of its
+// own: code that a scene never runs (rects, the scan, the tree walk) still costs the code that
+// does run registers and scheduling freedom when it shares a kernel with it.
+template <bool COUNT, bool LDS, bool PROF, int MODE, bool RECTS>
 __global__ __launch_bounds__(kBlock, RT_WG_PER_CU) void render_kernel(DScene sc, DCamera cam, DRender rp, float4* __restrict__ out,
                                                         unsigned long long* __restrict__ counters) {
+    constexpr bool SLICED = MODE == 2, BVH = MODE != 0;
     extern __shared__ __align__(16) int s_dyn[];
     int* stack = s_dyn + threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -959,11 +963,12 @@ __global__ __launch_bounds__(kBlock, RT_WG_PER_CU) void render_kernel(DScene sc,
                     hit_always<COUNT, RECTS>(sc, o, d, rn, rp.t_min, from, cq, cn);
                     nrays++;
                     depth++;
-                    if (!sc.use_bvh) hit_list<COUNT>(sc, o, rn, from, cq, cn);
+                    if constexpr (!BVH) hit_list<COUNT>(sc, o, rn, from, cq, cn);
                     else if (sc.root != kNoBvh) { hit_own_sphere(geo, o, rn, from, cq); curq = sc.root; spq = 0; }
                 }
                 if (PROF) { unsigned long long t = clk(); ph[1] += t - tq; tq = t; }
-                if (curq != kTravDone) hit_bvh<COUNT, SLICED>(geo, o, rn, from, stack, rp.slice, curq, spq, cq, cn);
+                if constexpr (BVH)
+                    if (curq != kTravDone) hit_bvh<COUNT, SLICED>(geo, o, rn, from, stack, rp.slice, curq, spq, cq, cn);
                 if (PROF) { unsigned long long t = clk(); ph[2] += t - tq; tq = t; }
                 if (curq == kTravDone) {                   // query finished (else: resumed next trip)
                     if (shade<COUNT, RECTS>(sc, geo, rp, cq, key, depth, refine, rn, o, d, T, L, from, cn)) {
@@ -1086,12 +1091,16 @@ hipError_t launch_render(const DScene& sc, const DCamera& cam, const DRender& rp
     if (r.slice == 0x7fffffff) r.slice = sc.bvh_depth > 12 ? 32 : 0;
     const bool sliced = sc.use_bvh && r.slice > 0;
 #define RT_LAUNCH(...) hipLaunchKernelGGL((render_kernel<__VA_ARGS__>), grid, block, lds, stream, sc, cam, r, out, counters)
-#define RT_LAUNCH_R(C, L, P, S) do { if (sc.n_rects > 0) RT_LAUNCH(C, L, P, S, true); else RT_LAUNCH(C, L, P, S, false); } while (0)
-#define RT_LAUNCH_S(C, L, P) do { if (sliced) RT_LAUNCH_R(C, L, P, true); else RT_LAUNCH_R(C, L, P, false); } while (0)
-    if (prof) { if (in_lds) RT_LAUNCH_S(false, true, true); else RT_LAUNCH_S(false, false, true); }
-    else if (count) { if (in_lds) RT_LAUNCH_S(true, true, false); else RT_LAUNCH_S(true, false, false); }
-    else { if (in_lds) RT_LAUNCH_S(false, true, false); else RT_LAUNCH_S(false, false, false); }
-#undef RT_LAUNCH_S
+#define RT_LAUNCH_R(C, L, P, M) do { if (sc.n_rects > 0) RT_LAUNCH(C, L, P, M, true); else RT_LAUNCH(C, L, P, M, false); } while (0)
+#define RT_LAUNCH_M(C, P) do { \
+        if (!sc.use_bvh) RT_LAUNCH_R(C, false, P, 0); \
+        else if (in_lds) { if (sliced) RT_LAUNCH_R(C, true, P, 2); else RT_LAUNCH_R(C, true, P, 1); } \
+        else { if (sliced) RT_LAUNCH_R(C, false, P, 2); else RT_LAUNCH_R(C, false, P, 1); } \
+    } while (0)
+    if (prof) RT_LAUNCH_M(false, true);
+    else if (count) RT_LAUNCH_M(true, false);
+    else RT_LAUNCH_M(false, false);
+#undef RT_LAUNCH_M
 #undef RT_LAUNCH_R
 #undef RT_LAUNCH
     return hipGetLastError();

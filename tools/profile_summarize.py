@@ -36,7 +36,7 @@ for name, ctrs in per_kernel.items():
 with open(os.path.join(dst, "c2_pmc_per_launch.json"), "w") as f:
     json.dump(out, f, indent=1)
 
-main = [n for n in out if "true, false, false" in n]
+main = [n for n in out if "render_kernel<false, true, false, 1, false>" in n]      # plain, LDS-resident BVH, no rects
 if main:
     c = out[main[0]]
     fetch_kb, write_kb = c.get("FETCH_SIZE", 0.0), c.get("WRITE_SIZE", 0.0)

@@ -18,6 +18,9 @@ c.upload_scene(S.flatten(S.rtiow_scene())); c.set_camera(**S.rtiow_camera(aspect
 run("C2", 1920, 1080, 100)
 c.upload_scene(S.flatten(S.rtiow_scene()), accel=api.RT_ACCEL_LIST)
 run("C2 list@20", 1920, 1080, 20)
+if os.environ.get("WITH_C3"):
+    c.upload_scene(S.flatten(S.cornell_scene(), background=S.RT_BG_SOLID)); c.set_camera(**S.cornell_camera(aspect).desc())
+    run("C3", 1920, 1080, 100)
 if os.environ.get("WITH_C4"):
     c.upload_scene(S.stress_flat(1000000), accel=api.RT_ACCEL_BVH); c.set_camera(**S.stress_camera(aspect).desc())
     run("C4@16", 3840, 2160, 16)
