@@ -468,6 +468,8 @@ int rt_upload_scene(rt_context* ctx, const rt_scene_desc* d) {
     s.bvh_depth = depth;
     s.use_bvh = use_bvh ? 1 : 0;
     s.ids_fit_16 = (d->n_prims < 65536 && d->n_mats < 65536) ? 1 : 0;
+    s.has_textures = 0;
+    for (const rt::DMaterial& m : mats) if (m.tex >= 0) s.has_textures = 1;
     s.n_wide = (int)wide.size();
     s.n_rects = (int)rects.size();
     s.background = d->background;

@@ -70,6 +70,7 @@ struct DScene {
     int bvh_depth;
     int use_bvh;          // 0: scan all ordinary spheres in order
     int ids_fit_16;       // every list position and material index is below 65536
+    int has_textures;     // some material reads a texture
     const DWide* wide;
     int n_wide;
     const DRect* rects;

@@ -286,8 +286,8 @@ __device__ __forceinline__ RayN normalise(V3 d, float t_min) {
 
 // Always-tested primitives: wide spheres (double) and rects.  They run first and tighten the
 // distance bound the BVH traversal prunes with.
-// RECTS = false compiles the rect code out (kernels for scenes of spheres only: the rect code is
-// never run there, but its registers and size slowed the sphere path by 3 %).
+// RECTS = false compiles the rect and the texture code out (kernels for scenes of plainly coloured
+// spheres: that code is never run there, but its registers and size slowed the sphere path by 3 %).
 template <bool COUNT, bool RECTS>
 __device__ __forceinline__ void hit_always(const DScene& sc, V3 o, V3 d, const RayN& rn, float t_min, Origin from,
                                            Cand& best, Counters& cn) {
@@ -784,7 +784,8 @@ __device__ __forceinline__ bool shade(const DScene& sc, const G& geo, const DRen
     // arithmetic and runs while they are in flight
     const int mat = c.kind == 0 ? geo.mat(c.idx) : ((!RECTS || c.kind == 1) ? sc.wide[c.idx].mat : sc.rects[c.idx].mat);
     const double4 s64 = c.kind == 0 ? sc.sph64[c.idx] : make_double4(0.0, 0.0, 0.0, 1.0);
-    const DMaterial m = sc.mats[mat];
+    DMaterial m = sc.mats[mat];
+    if (!RECTS) m.tex = -1;        // a kernel without the rect code serves scenes without textures too: none of that code is kept
     // one Philox block per scatter segment, shared by whichever material consumes it
     const uint4 w = philox4x32_10(key.pixel, key.sample, (uint32_t)depth, 0u, key.seed_lo, key.seed_hi);
     Rec r = make_record<RECTS>(sc, c, o, d, rn.inv_len, refine, m.tex >= 0, s64, mat);
@@ -1091,7 +1092,7 @@ hipError_t launch_render(const DScene& sc, const DCamera& cam, const DRender& rp
     if (r.slice == 0x7fffffff) r.slice = sc.bvh_depth > 12 ? 32 : 0;
     const bool sliced = sc.use_bvh && r.slice > 0;
 #define RT_LAUNCH(...) hipLaunchKernelGGL((render_kernel<__VA_ARGS__>), grid, block, lds, stream, sc, cam, r, out, counters)
-#define RT_LAUNCH_R(C, L, P, M) do { if (sc.n_rects > 0) RT_LAUNCH(C, L, P, M, true); else RT_LAUNCH(C, L, P, M, false); } while (0)
+#define RT_LAUNCH_R(C, L, P, M) do { if (sc.n_rects > 0 || sc.has_textures) RT_LAUNCH(C, L, P, M, true); else RT_LAUNCH(C, L, P, M, false); } while (0)
 #define RT_LAUNCH_M(C, P) do { \
         if (!sc.use_bvh) RT_LAUNCH_R(C, false, P, 0); \
         else if (in_lds) { if (sliced) RT_LAUNCH_R(C, true, P, 2); else RT_LAUNCH_R(C, true, P, 1); } \
