@@ -180,15 +180,21 @@ __device__ __forceinline__ bool rect_test(const DRect& r, float num, V3 o, V3 d,
 // bound of the fused form, proportional to |o/d|), so rounding can only add visits, never lose a
 // hit.
 struct SlabSigns { bool x, y, z; };                    // direction component negative
-__device__ __forceinline__ bool box_test(float bx0, float by0, float bz0, float bx1, float by1, float bz1,
-                                         V3 idir, V3 oid, SlabSigns neg, float slack, float tn_min, float tn_max, float& t_enter) {
-    float nx = fmaf(neg.x ? bx1 : bx0, idir.x, oid.x), fx = fmaf(neg.x ? bx0 : bx1, idir.x, oid.x);
-    float ny = fmaf(neg.y ? by1 : by0, idir.y, oid.y), fy = fmaf(neg.y ? by0 : by1, idir.y, oid.y);
-    float nz = fmaf(neg.z ? bz1 : bz0, idir.z, oid.z), fz = fmaf(neg.z ? bz0 : bz1, idir.z, oid.z);
+// the test proper, from the three planes the ray enters through and the three it leaves through
+__device__ __forceinline__ bool box_planes(float enter_x, float enter_y, float enter_z, float leave_x, float leave_y, float leave_z,
+                                           V3 idir, V3 oid, float slack, float tn_min, float tn_max, float& t_enter) {
+    float nx = fmaf(enter_x, idir.x, oid.x), fx = fmaf(leave_x, idir.x, oid.x);
+    float ny = fmaf(enter_y, idir.y, oid.y), fy = fmaf(leave_y, idir.y, oid.y);
+    float nz = fmaf(enter_z, idir.z, oid.z), fz = fmaf(leave_z, idir.z, oid.z);
     float tnear = fmaxf(fmaxf(fmaxf(nx, ny), nz), tn_min);
     float tfar = fminf(fminf(fminf(fx, fy), fz), tn_max);
     t_enter = tnear;
     return tnear <= fmaf(tfar, 1.0000005f, slack);
+}
+__device__ __forceinline__ bool box_test(float bx0, float by0, float bz0, float bx1, float by1, float bz1,
+                                         V3 idir, V3 oid, SlabSigns neg, float slack, float tn_min, float tn_max, float& t_enter) {
+    return box_planes(neg.x ? bx1 : bx0, neg.y ? by1 : by0, neg.z ? bz1 : bz0, neg.x ? bx0 : bx1, neg.y ? by0 : by1, neg.z ? bz0 : bz1,
+                      idir, oid, slack, tn_min, tn_max, t_enter);
 }
 
 // Per-ray constants of the slab test.  A direction component of zero (or too small for a finite
@@ -216,16 +222,31 @@ __device__ __forceinline__ SlabRay slab_ray(V3 o, V3 dh) {
 // workgroup makes at kernel start when the whole BVH and sphere list fit.
 struct GeoGlobal {
     static constexpr bool kPrefetchLeaf = true;
+    static constexpr bool kPlaneAddressed = false;
     const float4* nodes; const float4* sph; const int2* info;
+    __device__ __forceinline__ int root_ref(int root) const { return root; }
     __device__ __forceinline__ float4 node(int i, int q) const { return nodes[4 * (size_t)i + q]; }
     __device__ __forceinline__ float4 sphere(int i) const { return sph[i]; }
     __device__ __forceinline__ int obj(int i) const { return info[i].x; }
     __device__ __forceinline__ int mat(int i) const { return info[i].y; }
 };
+// The LDS copy of the nodes is laid out for the slab test: 64 bytes per node,
+//   [x: left lo, left hi, right lo, right hi][y: the same][z: the same][left ref, right ref, -, -]
+// so that the plane a ray enters a child's slab through sits at (axis base + 4 bytes if the
+// direction component is negative) and the plane it leaves through at that address with bit 2
+// flipped.  A lane reads the six planes of both children it needs through addresses that carry
+// its ray's signs, instead of reading all twelve and selecting; the selects were a fifth of the
+// node step's VALU time and LDS has bandwidth to spare.  Inner-node references are the nodes' LDS
+// byte addresses (node_base + index * 64), leaves keep their negative codes.
+typedef const float __attribute__((address_space(3))) lds_cfloat;
+typedef const int __attribute__((address_space(3))) lds_cint;
+typedef int __attribute__((address_space(3))) lds_int;
 struct GeoLds {
     static constexpr bool kPrefetchLeaf = false;
-    const float4* nodes; const float4* sph; const int* objs;     // all three point into LDS
-    __device__ __forceinline__ float4 node(int i, int q) const { return nodes[4 * i + q]; }
+    static constexpr bool kPlaneAddressed = true;
+    unsigned node_base;                                          // LDS byte address of node 0
+    const float4* sph; const int* objs;                          // both point into LDS
+    __device__ __forceinline__ int root_ref(int root) const { return root >= 0 ? (int)node_base + (root << 6) : root; }   // a tiny scene's root is a leaf
     __device__ __forceinline__ float4 sphere(int i) const { return sph[i]; }
     // list position and material share a word (both below 65536 in a scene that fits in LDS)
     __device__ __forceinline__ int obj(int i) const { return objs[i] & 0xffff; }
@@ -408,29 +429,52 @@ __device__ __forceinline__ void hit_bvh(const G& geo, V3 o, const RayN& rn, Orig
     const int self = from.sphere();
     const float tn_min = rn.tn_min;
     const SlabRay sr = slab_ray(o, dh);
+    unsigned enter_x = 0u, enter_y = 0u, enter_z = 0u;    // plane-addressed nodes: where this ray's entry planes sit in a node
+    if constexpr (G::kPlaneAddressed) {
+        enter_x = sr.neg.x ? 4u : 0u;
+        enter_y = sr.neg.y ? 20u : 16u;
+        enter_z = sr.neg.z ? 36u : 32u;
+    }
+    // the stack top as an LDS byte address: a push or pop is one add and one LDS access
+    constexpr unsigned kStackStride = kBlock * sizeof(int);
+    const unsigned bottom = (unsigned)(size_t)(__attribute__((address_space(3))) char*)stack;
+    unsigned top = bottom + (unsigned)sp * kStackStride;
     int wave_steps = 0;
     bool stop = false;
     while (cur != kTravDone && !stop) {
         while (cur >= 0 && !stop) {
             if (COUNT) { cn.steps++; if (first_active_lane()) cn.wave_steps++; }
-            float4 q0 = geo.node(cur, 0), q1 = geo.node(cur, 1), q2 = geo.node(cur, 2), q3 = geo.node(cur, 3);
-            int left = __float_as_int(q3.x), right = __float_as_int(q3.y);
+            int left, right;
             float tl, tr;
+            bool hl, hr;
             if (COUNT) cn.box += 2;
-            bool hl = box_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, sr.idir, sr.oid, sr.neg, sr.slack, tn_min, best.tn, tl);
-            bool hr = box_test(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, sr.idir, sr.oid, sr.neg, sr.slack, tn_min, best.tn, tr);
+            if constexpr (G::kPlaneAddressed) {
+                const unsigned ax = (unsigned)cur + enter_x, ay = (unsigned)cur + enter_y, az = (unsigned)cur + enter_z;
+                lds_cfloat* ex = (lds_cfloat*)ax; lds_cfloat* lx = (lds_cfloat*)(ax ^ 4u);
+                lds_cfloat* ey = (lds_cfloat*)ay; lds_cfloat* ly = (lds_cfloat*)(ay ^ 4u);
+                lds_cfloat* ez = (lds_cfloat*)az; lds_cfloat* lz = (lds_cfloat*)(az ^ 4u);
+                lds_cint* refs = (lds_cint*)((unsigned)cur + 48u);
+                left = refs[0]; right = refs[1];
+                hl = box_planes(ex[0], ey[0], ez[0], lx[0], ly[0], lz[0], sr.idir, sr.oid, sr.slack, tn_min, best.tn, tl);
+                hr = box_planes(ex[2], ey[2], ez[2], lx[2], ly[2], lz[2], sr.idir, sr.oid, sr.slack, tn_min, best.tn, tr);
+            } else {
+                float4 q0 = geo.node(cur, 0), q1 = geo.node(cur, 1), q2 = geo.node(cur, 2), q3 = geo.node(cur, 3);
+                left = __float_as_int(q3.x); right = __float_as_int(q3.y);
+                hl = box_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, sr.idir, sr.oid, sr.neg, sr.slack, tn_min, best.tn, tl);
+                hr = box_test(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, sr.idir, sr.oid, sr.neg, sr.slack, tn_min, best.tn, tr);
+            }
             // (a straight-line version of this step, with selects and unconditional stack traffic,
             // measured 1 % slower)
             if (hl && hr) {
                 bool left_first = tl <= tr;
-                stack[sp * kBlock] = left_first ? right : left;
-                sp++;
+                *(lds_int*)top = left_first ? right : left;
+                top += kStackStride;
                 cur = left_first ? left : right;
             } else if (hl || hr) {
                 cur = hl ? left : right;
-            } else if (sp > 0) {
-                sp--;
-                cur = stack[sp * kBlock];
+            } else if (top != bottom) {
+                top -= kStackStride;
+                cur = *(lds_int*)top;
             } else {
                 cur = kTravDone;
             }
@@ -446,14 +490,15 @@ __device__ __forceinline__ void hit_bvh(const G& geo, V3 o, const RayN& rn, Orig
             if (COUNT) { cn.steps++; if (first_active_lane()) cn.wave_steps++; }
             int code = ~cur;
             leaf_spheres<COUNT>(geo, code >> kLeafBits, (code & (kLeafCap - 1)) + 1, o, dh, tn_min, self, best, cn);
-            if (sp > 0) {
-                sp--;
-                cur = stack[sp * kBlock];
+            if (top != bottom) {
+                top -= kStackStride;
+                cur = *(lds_int*)top;
             } else {
                 cur = kTravDone;
             }
         }
     }
+    if constexpr (SLICED) sp = (int)((top - bottom) / kStackStride);
 }
 
 // Closest hit over the whole scene.
@@ -820,9 +865,18 @@ __device__ __forceinline__ typename GeoOf<LDS>::type stage_geometry(const DScene
         float4* nodes = reinterpret_cast<float4*>(lds);
         float4* sph = nodes + 4 * sc.n_nodes;
         int* objs = reinterpret_cast<int*>(sph + sc.n_sph);
-        for (int i = threadIdx.x; i < 4 * sc.n_nodes; i += kBlock) nodes[i] = sc.nodes[i];
+        const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)nodes;
+        for (int i = threadIdx.x; i < sc.n_nodes; i += kBlock) {
+            // device layout: left box lo xyz, hi xyz, right box lo xyz, hi xyz, left, right
+            const float4 q0 = sc.nodes[4 * i], q1 = sc.nodes[4 * i + 1], q2 = sc.nodes[4 * i + 2], q3 = sc.nodes[4 * i + 3];
+            const int l = __float_as_int(q3.x), r = __float_as_int(q3.y);
+            nodes[4 * i + 0] = make_float4(q0.x, q0.w, q1.z, q2.y);
+            nodes[4 * i + 1] = make_float4(q0.y, q1.x, q1.w, q2.z);
+            nodes[4 * i + 2] = make_float4(q0.z, q1.y, q2.x, q2.w);
+            nodes[4 * i + 3] = make_float4(__int_as_float(l >= 0 ? (int)base + (l << 6) : l), __int_as_float(r >= 0 ? (int)base + (r << 6) : r), 0.0f, 0.0f);
+        }
         for (int i = threadIdx.x; i < sc.n_sph; i += kBlock) { sph[i] = sc.sph[i]; int2 f = sc.sph_info[i]; objs[i] = f.x | (f.y << 16); }
-        GeoLds g = {nodes, sph, objs};
+        GeoLds g = {base, sph, objs};
         return g;
     } else {
         GeoGlobal g = {sc.nodes, sc.sph, sc.sph_info};
@@ -968,7 +1022,7 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? RT_WG_PER_CU_SCAN : RT_WG_PER_C
                     nrays++;
                     depth++;
                     if constexpr (!BVH) hit_list<COUNT>(sc, o, rn, from, cq, cn);
-                    else if (sc.root != kNoBvh) { hit_own_sphere(geo, o, rn, from, cq); curq = sc.root; spq = 0; }
+                    else if (sc.root != kNoBvh) { hit_own_sphere(geo, o, rn, from, cq); curq = geo.root_ref(sc.root); spq = 0; }
                 }
                 if (PROF) { unsigned long long t = clk(); ph[1] += t - tq; tq = t; }
                 if constexpr (BVH)
