@@ -127,6 +127,11 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", device))
         else:
             dist.init_process_group("gloo")
+        # the first gather on a communicator sets up its peer connections: done here, untimed,
+        # whatever --warmup is
+        probe = torch.zeros(16, device="cuda" if args.backend == "nccl" else "cpu")
+        dist.gather(probe, [torch.empty_like(probe) for _ in range(world)] if rank == 0 else None, dst=0)
+        dist.barrier()
 
     ctx = api.Context(device)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)

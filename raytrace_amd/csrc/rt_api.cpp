@@ -175,6 +175,8 @@ int validate_render(rt_context* ctx, const rt_render_params* p, rt::DRender* rp)
         // (tools/tune_probe.py); unset in normal use
         const char* v = std::getenv("RT_TUNE_SLICE");
         rp->slice = v && *v ? std::atoi(v) : 0x7fffffff;      // 0x7fffffff: chosen at launch from the tree depth
+        const char* q = std::getenv("RT_TUNE_QUORUM");
+        rp->leaf_quorum = q && *q ? std::atoi(q) : -1;       // -1: default ratio
     }
     return RT_OK;
 }

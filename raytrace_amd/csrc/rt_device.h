@@ -107,6 +107,7 @@ struct DRender {
     float inv_wm1, inv_hm1;                 // 1/(W-1), 1/(H-1)  (main.cc:117-118)
     int stack_depth;                        // entries per lane of the LDS traversal stack
     int slice;                              // node steps a wave spends on traversal per trip (0 = no limit, 0x7fffffff = choose at launch)
+    int leaf_quorum;                        // time-sliced walk: leaves are tested once (lanes waiting at a leaf) x this >= lanes still walking (0 = wait for all, -1 = default)
 };
 
 // counters[0] rays, [1] samples, [2] box tests, [3] sphere tests, [4] sphere hits,

@@ -423,7 +423,7 @@ __device__ __forceinline__ void hit_own_sphere(const G& geo, V3 o, const RayN& r
 constexpr int kTravDone = (int)0x80000000;     // not a leaf code: ~kTravDone >> 2 exceeds any sphere count
 
 template <bool COUNT, bool SLICED, class G>
-__device__ __forceinline__ void hit_bvh(const G& geo, V3 o, const RayN& rn, Origin from, int* stack, int budget,
+__device__ __forceinline__ void hit_bvh(const G& geo, V3 o, const RayN& rn, Origin from, int* stack, int budget, int quorum,
                                         int& cur, int& sp, Cand& best, Counters& cn) {
     const V3 dh = rn.dh;
     const int self = from.sphere();
@@ -442,7 +442,15 @@ __device__ __forceinline__ void hit_bvh(const G& geo, V3 o, const RayN& rn, Orig
     int wave_steps = 0;
     bool stop = false;
     while (cur != kTravDone && !stop) {
-        while (cur >= 0 && !stop) {
+        // Deep trees: a lane meets a leaf every seven or eight node steps, and waiting until all 64
+        // lanes stand on one leaves most of them idle for most of the walk.  The wave therefore
+        // turns to the leaves as soon as the lanes waiting at one, times `quorum`, outnumber the
+        // lanes still walking (both wave-uniform: built from ballots only); the walkers carry on
+        // afterwards.  Shallow trees keep the plain rule: there the two extra ballots per step
+        // cost more than the shorter waits return.
+        int waiting = SLICED ? __popcll(__ballot(cur < 0)) : 0;
+        bool leave = false;
+        while (cur >= 0 && !stop && !leave) {
             if (COUNT) { cn.steps++; if (first_active_lane()) cn.wave_steps++; }
             int left, right;
             float tl, tr;
@@ -450,10 +458,10 @@ __device__ __forceinline__ void hit_bvh(const G& geo, V3 o, const RayN& rn, Orig
             if (COUNT) cn.box += 2;
             if constexpr (G::kPlaneAddressed) {
                 const unsigned ax = (unsigned)cur + enter_x, ay = (unsigned)cur + enter_y, az = (unsigned)cur + enter_z;
-                lds_cfloat* ex = (lds_cfloat*)ax; lds_cfloat* lx = (lds_cfloat*)(ax ^ 4u);
-                lds_cfloat* ey = (lds_cfloat*)ay; lds_cfloat* ly = (lds_cfloat*)(ay ^ 4u);
-                lds_cfloat* ez = (lds_cfloat*)az; lds_cfloat* lz = (lds_cfloat*)(az ^ 4u);
-                lds_cint* refs = (lds_cint*)((unsigned)cur + 48u);
+                lds_cfloat* ex = (lds_cfloat*)(size_t)ax; lds_cfloat* lx = (lds_cfloat*)(size_t)(ax ^ 4u);
+                lds_cfloat* ey = (lds_cfloat*)(size_t)ay; lds_cfloat* ly = (lds_cfloat*)(size_t)(ay ^ 4u);
+                lds_cfloat* ez = (lds_cfloat*)(size_t)az; lds_cfloat* lz = (lds_cfloat*)(size_t)(az ^ 4u);
+                lds_cint* refs = (lds_cint*)(size_t)((unsigned)cur + 48u);
                 left = refs[0]; right = refs[1];
                 hl = box_planes(ex[0], ey[0], ez[0], lx[0], ly[0], lz[0], sr.idir, sr.oid, sr.slack, tn_min, best.tn, tl);
                 hr = box_planes(ex[2], ey[2], ez[2], lx[2], ly[2], lz[2], sr.idir, sr.oid, sr.slack, tn_min, best.tn, tr);
@@ -467,16 +475,20 @@ __device__ __forceinline__ void hit_bvh(const G& geo, V3 o, const RayN& rn, Orig
             // measured 1 % slower)
             if (hl && hr) {
                 bool left_first = tl <= tr;
-                *(lds_int*)top = left_first ? right : left;
+                *(lds_int*)(size_t)top = left_first ? right : left;
                 top += kStackStride;
                 cur = left_first ? left : right;
             } else if (hl || hr) {
                 cur = hl ? left : right;
             } else if (top != bottom) {
                 top -= kStackStride;
-                cur = *(lds_int*)top;
+                cur = *(lds_int*)(size_t)top;
             } else {
                 cur = kTravDone;
+            }
+            if constexpr (SLICED) {
+                waiting += __popcll(__ballot(cur < 0 && cur != kTravDone));
+                leave = waiting * quorum >= __popcll(__ballot(cur >= 0));
             }
             if constexpr (SLICED) {
                 // the count is taken from the first active lane; a lane that sat out some steps at
@@ -492,7 +504,7 @@ __device__ __forceinline__ void hit_bvh(const G& geo, V3 o, const RayN& rn, Orig
             leaf_spheres<COUNT>(geo, code >> kLeafBits, (code & (kLeafCap - 1)) + 1, o, dh, tn_min, self, best, cn);
             if (top != bottom) {
                 top -= kStackStride;
-                cur = *(lds_int*)top;
+                cur = *(lds_int*)(size_t)top;
             } else {
                 cur = kTravDone;
             }
@@ -511,7 +523,7 @@ __device__ __forceinline__ Cand closest_hit(const DScene& sc, V3 o, V3 d, float 
     if (!sc.use_bvh) hit_list<COUNT>(sc, o, rn, no_origin(), best, cn);
     else if (sc.root != kNoBvh) {
         int cur = sc.root, sp = 0;
-        hit_bvh<COUNT, false>(geo, o, rn, no_origin(), stack, 0, cur, sp, best, cn);
+        hit_bvh<COUNT, false>(geo, o, rn, no_origin(), stack, 0, 0, cur, sp, best, cn);
     }
     return best;
 }
@@ -1026,7 +1038,7 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? RT_WG_PER_CU_SCAN : RT_WG_PER_C
                 }
                 if (PROF) { unsigned long long t = clk(); ph[1] += t - tq; tq = t; }
                 if constexpr (BVH)
-                    if (curq != kTravDone) hit_bvh<COUNT, SLICED>(geo, o, rn, from, stack, rp.slice, curq, spq, cq, cn);
+                    if (curq != kTravDone) hit_bvh<COUNT, SLICED>(geo, o, rn, from, stack, rp.slice, rp.leaf_quorum, curq, spq, cq, cn);
                 if (PROF) { unsigned long long t = clk(); ph[2] += t - tq; tq = t; }
                 if (curq == kTravDone) {                   // query finished (else: resumed next trip)
                     if (shade<COUNT, RECTS>(sc, geo, rp, cq, key, depth, refine, rn, o, d, T, L, from, cn)) {
@@ -1148,6 +1160,8 @@ hipError_t launch_render(const DScene& sc, const DCamera& cam, const DRender& rp
     // Deep trees (large scenes) have a long-tailed traversal length: there a wave spends at most
     // `slice` node steps per trip on traversal and unfinished lanes resume on the next trip.
     if (r.slice == 0x7fffffff) r.slice = sc.bvh_depth > 12 ? 32 : 0;
+    if (r.leaf_quorum < 0) r.leaf_quorum = 2;
+
     const bool sliced = sc.use_bvh && r.slice > 0;
 #define RT_LAUNCH(...) hipLaunchKernelGGL((render_kernel<__VA_ARGS__>), grid, block, lds, stream, sc, cam, r, out, counters)
 #define RT_LAUNCH_R(C, L, P, M) do { if (sc.n_rects > 0 || sc.has_textures) RT_LAUNCH(C, L, P, M, true); else RT_LAUNCH(C, L, P, M, false); } while (0)
