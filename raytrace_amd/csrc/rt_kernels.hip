@@ -377,20 +377,25 @@ __device__ __forceinline__ void hit_list(const DScene& sc, V3 o, const RayN& rn,
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             // wave-uniform branch: skipped when no lane's line comes within the radius; inside,
-            // the rest of sphere_test without branches.  The scan runs in list order, so "later
-            // object wins an exact tie" is simply "accept when root <= closest so far".
+            // the rest of sphere_test without branches.  The scan runs in list order, so among
+            // spheres "later object wins an exact tie" is "accept when root <= closest so far".
             if (__ballot(gap[k] >= 0.0f) != 0ull) {
                 float thc = __builtin_amdgcn_sqrtf(fmaxf(gap[k], 0.0f));
                 float t0 = tca[k] - thc, t1 = tca[k] + thc;
                 const bool own = i + k == self;                   // the sphere this ray starts on
-                bool ok0 = t0 >= rn.tn_min && t0 <= best.tn && !own;
-                bool ok1 = t1 >= rn.tn_min && t1 <= best.tn && !(own && !self_in);
+                // an exact tie goes to the later list entry; the candidate so far is an earlier
+                // sphere or one of the always-tested primitives, which may come later in the list:
+                // then the bound is the next float below its distance
+                const int obj = info[2 * (i + k)];
+                const float lim = __int_as_float(__float_as_int(best.tn) - (obj > best.obj ? 0 : 1));
+                bool ok0 = t0 >= rn.tn_min && t0 <= lim && !own;
+                bool ok1 = t1 >= rn.tn_min && t1 <= lim && !(own && !self_in);
                 bool hit = gap[k] >= 0.0f && (ok0 || ok1);
                 if (COUNT && hit) cn.sph_hit++;
                 best.tn = hit ? (ok0 ? t0 : t1) : best.tn;
                 best.idx = hit ? i + k : best.idx;
                 best.kind = hit ? 0 : best.kind;
-                best.obj = hit ? info[2 * (i + k)] : best.obj;
+                best.obj = hit ? obj : best.obj;
             }
         }
     }

@@ -65,7 +65,15 @@ def _random_scene(S, rng):
     return flat, cam, scale, offset
 
 
-@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("RT_FUZZ_SEEDS", "40"))))
+# scenes that once disagreed, kept whatever the count: 5899 holds a ray that meets a sphere and a
+# rect at exactly the same single-precision distance (the scan took the sphere, the tree walk the
+# rect, which comes later in the list and is the one that wins a tie); 2161 has the longest glass
+# paths met so far
+_KEPT_SEEDS = [2161, 5899]
+_N_SEEDS = int(__import__("os").environ.get("RT_FUZZ_SEEDS", "40"))
+
+
+@pytest.mark.parametrize("seed", list(range(_N_SEEDS)) + [k for k in _KEPT_SEEDS if k >= _N_SEEDS])
 def test_random_scene(seed, oracle):
     from raytrace_amd import api, scene as S
     rng = np.random.default_rng(1000 + seed)
@@ -104,7 +112,10 @@ def test_random_scene(seed, oracle):
             assert np.array_equal(img, first), accel            # the frame does not depend on the strategy
         assert np.isfinite(img).all()
         # same keyed paths: float-vs-double branch flips are rare, so the images are close and
-        # the number of rays traced nearly equal
-        assert abs(st["rays"] - n_rays) <= max(20, 2e-3 * n_rays), (accel, st["rays"], n_rays)
+        # the number of rays traced nearly equal.  Over 1500 scenes the difference is centred on
+        # zero (298 positive, 303 negative, 899 equal; relative sd 1.8e-4, largest 1.5e-3); the
+        # tail comes from paths of 30-50 bounces inside glass balls, where one flipped
+        # reflect-or-refract draw changes the rest of the path (one scene in 4000 reached 2.6e-3)
+        assert abs(st["rays"] - n_rays) <= max(20, 4e-3 * n_rays), (accel, st["rays"], n_rays)
         peak = max(1.0, float(sums.max() / spp))
         assert np.sqrt(np.mean((img[..., :3] / spp - sums / spp) ** 2)) <= 0.02 * peak
