@@ -69,7 +69,7 @@ __device__ __forceinline__ bool better(float tn, int obj, const Cand& b) {
 // Sphere too large for the single-precision test (sphere.h:18-41), against the unit direction.
 // What single precision cannot do here is form |o - c|^2 - r^2 and (o - c).d without losing the
 // answer to cancellation (r = 1000: 0.06 of absolute error on a difference of a few units), so
-// those three sums and the discriminant are taken in double (13 operations).  The roots then
+// those three sums, |d|^2 and the discriminant are taken in double (17 operations).  The roots then
 // come from the cancellation-free form of the quadratic formula, q = -(hb + sign(hb) sqrt(disc)),
 // roots q and c / q, in single precision: each is good to a few ulps, like an ordinary sphere's,
 // and the winner is polished in double like an ordinary sphere's.
@@ -77,7 +77,10 @@ __device__ __forceinline__ bool wide_hit(const DWide& w, V3 o, V3 dh, float tn_m
     const double ocx = (double)o.x - w.cx, ocy = (double)o.y - w.cy, ocz = (double)o.z - w.cz;
     const double hb = fma(ocz, (double)dh.z, fma(ocy, (double)dh.y, ocx * (double)dh.x));
     const double cc = fma(ocz, ocz, fma(ocy, ocy, fma(ocx, ocx, -w.r2)));
-    const double disc = fma(hb, hb, -cc);              // |dh| = 1
+    // |dh|^2 is 1 only to single precision (1e-7), and that error is multiplied by cc: for a sphere
+    // seen from 30 radii away at a grazing angle it is as large as the discriminant itself
+    const double a = fma((double)dh.z, (double)dh.z, fma((double)dh.y, (double)dh.y, (double)dh.x * (double)dh.x));
+    const double disc = fma(hb, hb, -a * cc);
     if (disc < 0.0) return false;
     const float hbf = (float)hb, ccf = (float)cc;
     const float sq = __builtin_amdgcn_sqrtf((float)disc);

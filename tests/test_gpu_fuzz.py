@@ -68,12 +68,15 @@ def _random_scene(S, rng):
 # scenes that once disagreed, kept whatever the count: 5899 holds a ray that meets a sphere and a
 # rect at exactly the same single-precision distance (the scan took the sphere, the tree walk the
 # rect, which comes later in the list and is the one that wins a tie); 2161 has the longest glass
-# paths met so far
-_KEPT_SEEDS = [2161, 5899]
+# paths met so far; 14114 sees a sphere of radius 210 from 34 radii away at a grazing angle, where
+# |unit direction|^2 - 1 (1e-7) times the squared distance is as large as the discriminant
+_KEPT_SEEDS = [2161, 5899, 14114]
 _N_SEEDS = int(__import__("os").environ.get("RT_FUZZ_SEEDS", "40"))
+_FIRST_SEED = int(__import__("os").environ.get("RT_FUZZ_FIRST", "0"))          # long runs by hand, in parts
 
 
-@pytest.mark.parametrize("seed", list(range(_N_SEEDS)) + [k for k in _KEPT_SEEDS if k >= _N_SEEDS])
+@pytest.mark.parametrize("seed", list(range(_FIRST_SEED, _FIRST_SEED + _N_SEEDS)) +
+                         [k for k in _KEPT_SEEDS if not _FIRST_SEED <= k < _FIRST_SEED + _N_SEEDS])
 def test_random_scene(seed, oracle):
     from raytrace_amd import api, scene as S
     rng = np.random.default_rng(1000 + seed)

@@ -6,7 +6,7 @@ from test_gpu_fuzz import _random_scene, _unit
 from raytrace_amd import api, scene as S
 from oracle.pyoracle import Oracle
 oracle = Oracle("f64")
-for seed in (281,):
+for seed in (int(os.environ.get("SEED", "281")),):
     rng = np.random.default_rng(1000 + seed)
     flat, cam, scale, offset = _random_scene(S, rng)
     cd = oracle.camera(**cam)
@@ -15,7 +15,7 @@ for seed in (281,):
         o = offset + rng.uniform(-6, 6, 3) * scale * [1, 0.3, 1] + [0, 1.5 * scale, 0]
         rays.append(np.concatenate([o, _unit(rng.normal(size=3)) * rng.uniform(0.3, 2)]))
     rays = np.asarray(rays, np.float64).astype(np.float32).astype(np.float64)
-    want = oracle.trace(flat, rays)
+    want = oracle.trace(flat, rays, t_min=0.001)
     ctx = api.Context(0); ctx.upload_scene(flat, accel=api.RT_ACCEL_BVH); h = ctx.trace_primary(rays)
     ok = (h["id"] == want["id"]) & (want["id"] >= 0)
     rel = np.where(ok, np.abs(h["n"] - want["n"]).max(axis=1), 0)
