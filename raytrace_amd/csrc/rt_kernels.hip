@@ -587,16 +587,23 @@ __device__ __forceinline__ Rec make_record(const DScene& sc, const Cand& c, V3 o
         r.p = madd(o, t, d);
         V3 axis = mk(ka == 0 ? 1.0f : 0.0f, ka == 1 ? 1.0f : 0.0f, ka == 2 ? 1.0f : 0.0f);
         V3 po = r.p;
+        // the hit lies in the rect's plane: that coordinate of the point is k itself (as the
+        // reference's o + t d is to 1e-12), not a single-precision o + t d, which strays by an ulp
+        // of the scene's coordinates and lets a solid texture flip where it changes across the plane
         if (q.axes >> 8) {
             // the instance's own hit record, then point and normal back in the world.  The side
             // of the surface is the one the instance saw (cuda/sceneobject.h:105 asks again with
             // the object-space ray against the world-space normal, which mixes the two frames).
             const DXform x = sc.xforms[(q.axes >> 8) - 1];
-            ObjRay oq = to_object(x, o, d, ka, sc.rect_k[c.idx]);
+            const double kd = sc.rect_k[c.idx];
+            ObjRay oq = to_object(x, o, d, ka, kd);
             po = madd(oq.o, t, oq.d);
+            const double pox = ka == 0 ? kd : (double)po.x, poy = ka == 1 ? kd : (double)po.y, poz = ka == 2 ? kd : (double)po.z;
+            r.p = mk((float)(fma(x.c, pox, x.s * poz) + x.tx), (float)(poy + x.ty), (float)(fma(-x.s, pox, x.c * poz) + x.tz));
             face(r, oq.d, axis);
             r.n = to_world_dir(x, r.n);
         } else {
+            if (ka == 0) r.p.x = q.k; else if (ka == 1) r.p.y = q.k; else r.p.z = q.k;      // q.k is k rounded to float
             face(r, d, axis);
         }
         r.u = (comp(po, aa) - q.a0) / (q.a1 - q.a0);
