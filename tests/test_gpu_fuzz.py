@@ -110,6 +110,27 @@ def test_random_scene(seed, oracle):
         assert np.array_equal(hits["front_face"][ok], want["front"][ok])
         img = ctx.render_host(api.Context.params(W, H, spp, 50, 77 + seed))
         st = ctx.stats()
+        if accel != api.RT_ACCEL_LIST:
+            # the same tree read from HBM instead of LDS, and walked in time slices (what scenes too
+            # large for LDS and trees deeper than 12 levels get): the same frame, the same ray count
+            import os
+            for flags, slice_steps in ((api.RT_FLAG_NO_LDS_SCENE, None), (0, "3"), (api.RT_FLAG_NO_LDS_SCENE, "5")):
+                if slice_steps is not None:
+                    os.environ["RT_TUNE_SLICE"] = slice_steps
+                try:
+                    other = ctx.render_host(api.Context.params(W, H, spp, 50, 77 + seed, flags=flags))
+                finally:
+                    os.environ.pop("RT_TUNE_SLICE", None)
+                assert np.array_equal(other, img), (accel, flags, slice_steps)
+                assert ctx.stats()["rays"] == st["rays"]
+        if accel == api.RT_ACCEL_BVH:
+            # three interleaved shards of 4-row tiles, another tile shape: the same bits
+            whole = np.zeros_like(img)
+            for g in range(3):
+                part = ctx.render_host(api.Context.params(W, H, spp, 50, 77 + seed, tiles=(4, g, 3), lanes_per_pixel=16))
+                rows = [r for t in range(g, H // 4, 3) for r in range(4 * t, 4 * t + 4)]
+                whole[rows] = part
+            assert np.array_equal(whole, img)
         ctx.close()
         if first is None:
             first = img
