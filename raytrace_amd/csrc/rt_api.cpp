@@ -318,6 +318,14 @@ int rt_upload_scene(rt_context* ctx, const rt_scene_desc* d) {
         if (m.tex < 0) m.tex = -1;
         if ((m.type == RT_METAL || m.type == RT_DIELECTRIC) && m.tex >= 0) m.tex = -1;   // neither reads a texture
         if (m.type == RT_DIELECTRIC && !(m.ir > 0.0f)) return fail(ctx, RT_ERR_INVALID, "dielectric needs ir > 0");
+        if (m.type == RT_DIELECTRIC) {
+            // material.h:61,88-90 per material instead of per hit: the refraction ratio seen from
+            // outside and Schlick's r0 for either side, in the same single-precision operations
+            // the kernel would use (a dielectric has no colour, so they take the colour's place)
+            const float inv_ir = 1.0f / m.ir;
+            const float r0_front = (1.0f - inv_ir) / (1.0f + inv_ir), r0_back = (1.0f - m.ir) / (1.0f + m.ir);
+            m.r = inv_ir; m.g = r0_front * r0_front; m.b = r0_back * r0_back;
+        }
     }
 
     // instance transforms: sine and cosine in double (cuda/sceneobject.h:50-52 takes them in float)

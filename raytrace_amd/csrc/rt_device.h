@@ -41,7 +41,7 @@ struct DRect {            // cuda/rect.h: plane axis `ka` at k, in-plane axes (a
 
 struct DMaterial {        // tagged union: material.h:15-92, cuda/material.h:33-47,103-119
     int type, tex;
-    float r, g, b;        // albedo / emitted colour when tex < 0
+    float r, g, b;        // albedo / emitted colour when tex < 0; dielectric: 1/ir, Schlick r0 seen from outside, from inside
     float fuzz, ir, pad;
 };
 

@@ -774,12 +774,11 @@ __device__ __forceinline__ bool scatter(const DScene& sc, const DMaterial& m, V3
     }
     case 2: {                                          // dielectric, material.h:58-91
         att = mk(1.0f, 1.0f, 1.0f);
-        float ratio = r.front ? (1.0f / m.ir) : m.ir;
+        float ratio = r.front ? m.r : m.ir;            // m.r = 1 / ir, m.g / m.b = r0 for this side (set at upload)
         float cos_theta = fminf(dot(-ud, r.n), 1.0f);
         float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
         bool tir = ratio * sin_theta > 1.0f;
-        float r0 = (1.0f - ratio) / (1.0f + ratio);
-        r0 = r0 * r0;
+        float r0 = r.front ? m.g : m.b;                // ((1 - ratio) / (1 + ratio))^2
         float x = 1.0f - cos_theta;
         float x2 = x * x;
         float refl_prob = r0 + (1.0f - r0) * (x2 * x2 * x);
