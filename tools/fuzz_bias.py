@@ -3,7 +3,7 @@ import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-from test_gpu_fuzz import _random_scene
+from test_gpu_fuzz import _random_scene, _random_field
 from raytrace_amd import api, scene as S
 from oracle.pyoracle import Oracle
 oracle = Oracle("f64")
@@ -12,8 +12,12 @@ W, H, spp = 72, 48, 8
 diffs, rels = [], []
 ctx = api.Context(0)
 for seed in range(lo, hi):
-    rng = np.random.default_rng(1000 + seed)
-    flat, cam, scale, offset = _random_scene(S, rng)
+    if os.environ.get("FIELD"):
+        rng = np.random.default_rng(50000 + seed)
+        flat, cam, scale, offset, side = _random_field(S, rng)
+    else:
+        rng = np.random.default_rng(1000 + seed)
+        flat, cam, scale, offset = _random_scene(S, rng)
     cd = oracle.camera(**cam)
     _, n_o = oracle.render(flat, cd, W, H, spp, 50, 77 + seed, threads=8)
     ctx.upload_scene(flat, accel=api.RT_ACCEL_BVH); ctx.set_camera(**cam)

@@ -4,13 +4,17 @@ import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-from test_gpu_fuzz import _random_scene
+from test_gpu_fuzz import _random_scene, _random_field
 from raytrace_amd import api, scene as S
 from oracle.pyoracle import Oracle
 oracle = Oracle("f64")
 seed = int(os.environ.get("SEED", "2161"))
-rng = np.random.default_rng(1000 + seed)
-flat, cam, scale, offset = _random_scene(S, rng)
+if os.environ.get("FIELD"):
+    rng = np.random.default_rng(50000 + seed)
+    flat, cam, scale, offset, side = _random_field(S, rng)
+else:
+    rng = np.random.default_rng(1000 + seed)
+    flat, cam, scale, offset = _random_scene(S, rng)
 cd = oracle.camera(**cam)
 W, H, spp = 72, 48, 8
 ctx = api.Context(0); ctx.upload_scene(flat, accel=api.RT_ACCEL_BVH); ctx.set_camera(**cam)
@@ -43,5 +47,8 @@ for (j, i) in bad:
     pid = int(hit["id"][0]) if hit is not None else -2
     print(f"pixel ({i},{j}) differs from depth limit {first}; centre ray sees prim {pid}"
           + (f" type {flat.prim_type[pid]} mat {flat.prim_mat[pid] if hasattr(flat, 'prim_mat') else '?'} geom {np.round(flat.prim_geom[pid][:6], 3)}" if pid >= 0 else ""))
+import collections
+hist = collections.Counter(next((D for D in sorted(per_depth) if per_depth[D][0][j, i]), None) for (j, i) in bad)
+print("first differing depth limit -> pixels:", sorted(hist.items(), key=lambda kv: (kv[0] is None, kv[0])))
 print("ray count diff by depth limit:", {D: int(v[1]) for D, v in per_depth.items()})
 print("aperture", cam["aperture"])
