@@ -72,7 +72,7 @@ def _random_scene(S, rng):
 # |unit direction|^2 - 1 (1e-7) times the squared distance is as large as the discriminant
 # 18788 has a checker texture that changes sign across a rect's plane within an ulp of the plane's
 # coordinate
-_KEPT_SEEDS = [2161, 5899, 14114, 18788]
+_KEPT_SEEDS = [2161, 5899, 14114, 18788, 56104]        # 56104: a root 6.6e-7 above t_min
 _N_SEEDS = int(__import__("os").environ.get("RT_FUZZ_SEEDS", "40"))
 _FIRST_SEED = int(__import__("os").environ.get("RT_FUZZ_FIRST", "0"))          # long runs by hand, in parts
 
@@ -99,6 +99,10 @@ def test_random_scene(seed, oracle):
         ctx.set_camera(**cam)
         hits = ctx.trace_primary(rays)
         bad = hits["id"] != want["id"]
+        # a root within a part in a thousand of t_min is the other kind of ray single precision cannot
+        # decide like double (the sphere records are rounded to float: 2e-7 of the coordinates):
+        # the same sphere is then hit at its far side instead; counted with the silhouette rays
+        bad |= (np.minimum(hits["t"], want["t"]) < 0.001 * 1.001) & (want["id"] >= 0)
         assert bad.sum() <= 3, (accel, int(bad.sum()), np.where(bad)[0][:5], hits["id"][bad][:5], want["id"][bad][:5])
         # a ray that grazes its sphere closer than cos = 1e-3 has no well-defined t in single
         # precision (the golden rays keep clear of silhouettes for the same reason)
@@ -191,6 +195,10 @@ def test_random_sphere_field(seed, oracle):
         ctx.set_camera(**cam)
         hits = ctx.trace_primary(rays)
         bad = hits["id"] != want["id"]
+        # a root within a part in a thousand of t_min is the other kind of ray single precision cannot
+        # decide like double (the sphere records are rounded to float: 2e-7 of the coordinates):
+        # the same sphere is then hit at its far side instead; counted with the silhouette rays
+        bad |= (np.minimum(hits["t"], want["t"]) < 0.001 * 1.001) & (want["id"] >= 0)
         assert bad.sum() <= 3, (accel, int(bad.sum()), np.where(bad)[0][:5], hits["id"][bad][:5], want["id"][bad][:5])
         cos = np.abs(np.sum(want["n"] * _unit(rays[:, 3:]), axis=1))
         ok = ~bad & (want["id"] >= 0) & (cos > 1e-3)

@@ -19,6 +19,8 @@ for seed in (int(os.environ.get("SEED", "281")),):
     ctx = api.Context(0); ctx.upload_scene(flat, accel=api.RT_ACCEL_BVH); h = ctx.trace_primary(rays)
     ok = (h["id"] == want["id"]) & (want["id"] >= 0)
     rel = np.where(ok, np.abs(h["n"] - want["n"]).max(axis=1), 0)
+    if os.environ.get("BY_T"):
+        rel = np.where(ok, np.abs(h["t"] - want["t"]) / np.maximum(np.abs(want["t"]), 1e-30), 0)
     for i in np.argsort(rel)[-3:]:
         pid = want["id"][i]
         print(f"seed {seed} scale {scale} ray {i}: prim {pid} type {flat.prim_type[pid]} geom {flat.prim_geom[pid][:5]} xf {flat.prim_xform[pid]} t want {want['t'][i]:.9g} got {h['t'][i]:.9g} n want {want['n'][i]} got {h['n'][i]} err {rel[i]:.2e} o {rays[i][:3]} d {rays[i][3:]}")
