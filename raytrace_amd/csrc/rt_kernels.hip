@@ -355,8 +355,8 @@ __device__ __forceinline__ void hit_always(const DScene& sc, V3 o, V3 d, const R
 // screened per trip with the branch-free part of the test (is the centre closer to the ray's
 // line than the radius?) and only a group in which some lane passes runs the full test.  The
 // array is padded to a multiple of four with spheres nothing can hit.
-template <bool COUNT>
-__device__ __forceinline__ void hit_list(const DScene& sc, V3 o, const RayN& rn, Origin from, Cand& best, Counters& cn) {
+template <bool COUNT, bool STAGED>
+__device__ __forceinline__ void hit_list(const DScene& sc, const float4* staged, V3 o, const RayN& rn, Origin from, Cand& best, Counters& cn) {
     const int self = from.sphere();
     const bool self_in = from.inward();
     // constant address space: tells the compiler nothing in the kernel writes these records, which
@@ -370,7 +370,14 @@ __device__ __forceinline__ void hit_list(const DScene& sc, V3 o, const RayN& rn,
         float tca[4], gap[4];                          // gap = r^2 - (distance of the centre from the line)^2
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const float sx = sph[4 * (i + k)], sy = sph[4 * (i + k) + 1], sz = sph[4 * (i + k) + 2], sr = sph[4 * (i + k) + 3];
+            float sx, sy, sz, sr;
+            if constexpr (STAGED) {
+                // from the workgroup's LDS copy: every lane reads the same address (a broadcast)
+                const float4 s4 = staged[i + k];
+                sx = s4.x; sy = s4.y; sz = s4.z; sr = s4.w;
+            } else {
+                sx = sph[4 * (i + k)]; sy = sph[4 * (i + k) + 1]; sz = sph[4 * (i + k) + 2]; sr = sph[4 * (i + k) + 3];
+            }
             V3 L = mk(sx - o.x, sy - o.y, sz - o.z);
             tca[k] = dot(L, dh);
             V3 l = madd(L, -tca[k], dh);
@@ -528,7 +535,7 @@ __device__ __forceinline__ Cand closest_hit(const DScene& sc, V3 o, V3 d, float 
     RayN rn = normalise(d, t_min);
     hit_always<COUNT, true>(sc, o, d, rn, t_min, no_origin(), best, cn);
     GeoGlobal geo = {sc.nodes, sc.sph, sc.sph_info};
-    if (!sc.use_bvh) hit_list<COUNT>(sc, o, rn, no_origin(), best, cn);
+    if (!sc.use_bvh) hit_list<COUNT, false>(sc, nullptr, o, rn, no_origin(), best, cn);
     else if (sc.root != kNoBvh) {
         int cur = sc.root, sp = 0;
         hit_bvh<COUNT, false>(geo, o, rn, no_origin(), stack, 0, 0, cur, sp, best, cn);
@@ -890,7 +897,7 @@ __device__ __forceinline__ typename GeoOf<LDS>::type stage_geometry(const DScene
     if constexpr (LDS) {
         float4* nodes = reinterpret_cast<float4*>(lds);
         float4* sph = nodes + 4 * sc.n_nodes;
-        int* objs = reinterpret_cast<int*>(sph + sc.n_sph);
+        int* objs = reinterpret_cast<int*>(sph + sc.n_sph_padded);
         const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)nodes;
         for (int i = threadIdx.x; i < sc.n_nodes; i += kBlock) {
             // device layout: left box lo xyz, hi xyz, right box lo xyz, hi xyz, left, right
@@ -902,6 +909,7 @@ __device__ __forceinline__ typename GeoOf<LDS>::type stage_geometry(const DScene
             nodes[4 * i + 3] = make_float4(__int_as_float(l >= 0 ? (int)base + (l << 6) : l), __int_as_float(r >= 0 ? (int)base + (r << 6) : r), 0.0f, 0.0f);
         }
         for (int i = threadIdx.x; i < sc.n_sph; i += kBlock) { sph[i] = sc.sph[i]; int2 f = sc.sph_info[i]; objs[i] = f.x | (f.y << 16); }
+        for (int i = sc.n_sph + threadIdx.x; i < sc.n_sph_padded; i += kBlock) { sph[i] = sc.sph[i]; objs[i] = 0; }   // the scan's padding
         GeoLds g = {base, sph, objs};
         return g;
     } else {
@@ -947,6 +955,8 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? RT_WG_PER_CU_SCAN : RT_WG_PER_C
     // pixel table: (x, j) of the tile's q-th pixel, x = -1 where the tile hangs over the image
     int2* tile_pix = reinterpret_cast<int2*>(accum + 3 * P);
     const auto geo = stage_geometry<LDS>(sc, s_dyn + rp.stack_depth * kBlock + (kBlock / 64) * accum_words * 2);
+    const float4* staged_list = geo.sph;               // the scan reads it when LDS (else it takes the records through scalar loads)
+    (void)staged_list;
     __syncthreads();
 
     const int logP = 31 - __clz(P);
@@ -1047,7 +1057,7 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? RT_WG_PER_CU_SCAN : RT_WG_PER_C
                     hit_always<COUNT, RECTS>(sc, o, d, rn, rp.t_min, from, cq, cn);
                     nrays++;
                     depth++;
-                    if constexpr (!BVH) hit_list<COUNT>(sc, o, rn, from, cq, cn);
+                    if constexpr (!BVH) hit_list<COUNT, LDS>(sc, staged_list, o, rn, from, cq, cn);
                     else if (sc.root != kNoBvh) { hit_own_sphere(geo, o, rn, from, cq); curq = geo.root_ref(sc.root); spq = 0; }
                 }
                 if (PROF) { unsigned long long t = clk(); ph[1] += t - tq; tq = t; }
@@ -1165,8 +1175,13 @@ hipError_t launch_render(const DScene& sc, const DCamera& cam, const DRender& rp
     DRender r = rp;
     r.stack_depth = sc.use_bvh ? sc.bvh_depth + 1 : 1;   // one push per inner level at most
     size_t lds = (size_t)r.stack_depth * kBlock * sizeof(int) + (size_t)(kBlock / 64) * 4 * (64 / rp.lanes_per_pixel) * sizeof(unsigned long long);
-    const size_t geo_bytes = (size_t)sc.n_nodes * 64 + (size_t)sc.n_sph * 20;
-    const bool in_lds = (rp.flags & 32u) == 0u && sc.use_bvh && sc.n_sph > 0 && lds + geo_bytes <= 40 * 1024 && sc.ids_fit_16;
+    const size_t geo_bytes = (size_t)sc.n_nodes * 64 + (size_t)sc.n_sph_padded * 20;
+    // the tree walk keeps tree and spheres in LDS up to 40 KB per workgroup.  The scan reads a
+    // short list (a room with a few balls) from LDS: 6 % faster than through scalar loads, whose
+    // latency a loop of one or two trips cannot hide; a long list is faster through scalar loads
+    // (487 spheres: by 6 %), which run ahead of the arithmetic and cost no vector registers
+    const bool in_lds = (rp.flags & 32u) == 0u && sc.n_sph > 0 &&
+                        (sc.use_bvh ? lds + geo_bytes <= 40 * 1024 && sc.ids_fit_16 : sc.n_sph_padded <= 32);
     if (in_lds) lds += geo_bytes;
     const bool count = (rp.flags & 4u) != 0u;
     const bool prof = (rp.flags & 8u) != 0u;
@@ -1180,7 +1195,7 @@ hipError_t launch_render(const DScene& sc, const DCamera& cam, const DRender& rp
 #define RT_LAUNCH(...) hipLaunchKernelGGL((render_kernel<__VA_ARGS__>), grid, block, lds, stream, sc, cam, r, out, counters)
 #define RT_LAUNCH_R(C, L, P, M) do { if (sc.n_rects > 0 || sc.has_textures) RT_LAUNCH(C, L, P, M, true); else RT_LAUNCH(C, L, P, M, false); } while (0)
 #define RT_LAUNCH_M(C, P) do { \
-        if (!sc.use_bvh) RT_LAUNCH_R(C, false, P, 0); \
+        if (!sc.use_bvh) { if (in_lds) RT_LAUNCH_R(C, true, P, 0); else RT_LAUNCH_R(C, false, P, 0); } \
         else if (in_lds) { if (sliced) RT_LAUNCH_R(C, true, P, 2); else RT_LAUNCH_R(C, true, P, 1); } \
         else { if (sliced) RT_LAUNCH_R(C, false, P, 2); else RT_LAUNCH_R(C, false, P, 1); } \
     } while (0)

@@ -43,6 +43,10 @@ typedef float float2v __attribute__((ext_vector_type(2)));
 #define OP_CMP(x) asm volatile("v_cmp_le_f32 vcc, %0, %1" : : "v"(x), "v"(a) : "vcc")
 #define OP_CMPS(x) asm volatile("v_cmp_le_f32 s[20:21], %0, %1" : : "v"(x), "v"(a) : "s20", "s21")
 #define OP_MOV(x) asm volatile("v_mov_b32 %0, %1" : "+v"(x) : "v"(a))
+#define OP_FMAMK(x) asm volatile("v_fmamk_f32 %0, %0, 0x3f800004, %1" : "+v"(x) : "v"(a))
+#define OP_FMAINL(x) asm volatile("v_fma_f32 %0, %0, 1.0, %1" : "+v"(x) : "v"(a))
+#define OP_ADDLIT(x) asm volatile("v_add_f32 %0, 0x3f800004, %0" : "+v"(x))
+#define OP_MAX3S(x) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(x) : "v"(a), "v"(b))
 #define OP_RCP(x) asm volatile("v_rcp_f32 %0, %0" : "+v"(x))
 #define OP_SQRT(x) asm volatile("v_sqrt_f32 %0, %0" : "+v"(x))
 KERNEL(k_fma, DECL_F, OP_FMA) KERNEL(k_add, DECL_F, OP_ADD) KERNEL(k_mul, DECL_F, OP_MUL) KERNEL(k_min, DECL_F, OP_MIN)
@@ -79,6 +83,8 @@ KERNEL(k_cvt, DECL_I, OP_CVT) KERNEL(k_cvtw, DECL_I, OP_CVTW)
 KERNEL(k_iadd, DECL_I, OP_IADD) KERNEL(k_and, DECL_I, OP_AND) KERNEL(k_xor, DECL_I, OP_XOR3) KERNEL(k_lshladd, DECL_I, OP_LSHLADD)
 KERNEL(k_mullo, DECL_I, OP_MULLO) KERNEL(k_mulhi, DECL_I, OP_MULHI) KERNEL(k_align, DECL_I, OP_ALIGN)
 
+KERNEL(k_fmamk, DECL_F, OP_FMAMK) KERNEL(k_fmainl, DECL_F, OP_FMAINL) KERNEL(k_addlit, DECL_F, OP_ADDLIT)
+
 typedef void (*kern_t)(float*, int, float, float);
 void run(const char* name, kern_t k, int waves_per_simd, double flops_per_inst) {
     int iters = 4000, blocks = 256 * waves_per_simd;
@@ -106,6 +112,7 @@ int main() {
     run("cmp+cnd vcc (2 inst)", k_cndw, w, 0); run("cmp+add+cnd vcc (3)", k_cndw2, w, 0); run("cmp+cnd sgpr (2 inst)", k_cnds, w, 0); run("v_mov v,s", k_vmovs, w, 0);
     run("v_cndmask", k_cnd, w, 0); run("v_cndmask e64 sgpr", k_cnd3, w, 0); run("v_cndmask 0,v", k_cndi, w, 0); run("v_max_f32", k_max, w, 1); run("v_sub_f32", k_sub, w, 1);
     run("v_fmac_f32", k_fmac, w, 2); run("v_fma sgpr ops", k_fmas, w, 2); run("v_min sgpr", k_mins, w, 1); run("v_cmp->vcc", k_cmp, w, 0); run("v_cmp->sgpr", k_cmps, w, 0); run("v_mov_b32", k_mov, w, 0);
+    run("v_fmamk literal", k_fmamk, w, 2); run("v_fma inline 1.0", k_fmainl, w, 2); run("v_add literal", k_addlit, w, 1);
     run("v_rcp_f32", k_rcp, w, 1); run("v_sqrt_f32", k_sqrt, w, 1);
     run("v_pk_fma_f32", k_pkfma, w, 4); run("v_pk_mul_f32", k_pkmul, w, 2); run("v_pk_add_f32", k_pkadd, w, 2);
     run("v_fma_f64", k_dfma, w, 2); run("v_mul_f64", k_dmul, w, 1); run("v_add_f64", k_dadd, w, 1);
