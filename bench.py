@@ -49,19 +49,19 @@ def measured_traffic():
 
 def cpu_baseline():
     """The reference's own main.cc (compiled into oracle/_ref) on one host core, on a bounded
-    sample of the same frame: every 4th pixel of every 4th row, 16 spp, glibc rand() like the
+    sample of the same frame: every 3rd pixel of every 3rd row, 16 spp (about 11 s), glibc rand() like the
     original binary.  Falls back to the C restatement when the compiled reference is absent."""
     import numpy as np
     from oracle.pyoracle import Oracle, Reference
     from raytrace_amd import scene as S
     aspect = float(np.float32(W / H))
-    sample = f"{W}x{H} frame, every 4th pixel of every 4th row, 16 spp, depth {DEPTH}, 1 thread"
+    sample = f"{W}x{H} frame, every 3rd pixel of every 3rd row, 16 spp, depth {DEPTH}, 1 thread"
     if Reference.available():
         ref = Reference()
         ref.load_scene(S.rtiow_records())
         ref.set_camera((6, 3, -13), (0, 0, 0), (0, 1, 0), 20.0, aspect, 0.1, 10.0)
         t0 = time.perf_counter()
-        _, rays = ref.render_libc(W, H, 16, DEPTH, step=(4, 4))
+        _, rays = ref.render_libc(W, H, 16, DEPTH, step=(3, 3))
         dt = time.perf_counter() - t0
         kind = "reference"
     else:
@@ -69,7 +69,7 @@ def cpu_baseline():
         flat = S.flatten(S.rtiow_scene())
         cam = orc.camera((6, 3, -13), (0, 0, 0), (0, 1, 0), 20.0, aspect, 0.1, 10.0)
         t0 = time.perf_counter()
-        _, rays = orc.render(flat, cam, W, H, 16, DEPTH, SEED, step=(4, 4), threads=1)
+        _, rays = orc.render(flat, cam, W, H, 16, DEPTH, SEED, step=(3, 3), threads=1)
         dt = time.perf_counter() - t0
         kind = "port"
     return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": 1, "kind": kind, "sample": sample,
