@@ -121,16 +121,15 @@ int shard_rows(int height, int tile_rows, int tile_first, int tile_step) {
 }
 
 int choose_lanes_per_pixel(long long pixels, int spp) {
-    // A wave's tile holds 64/K pixels.  K = 4 (an 8x2 tile, four samples of a pixel in flight at
+    // A wave's tile holds 64/K pixels.  K = 8 (an 8x1 tile, eight samples of a pixel in flight at
     // once) measured best on whole 1080p frames: the lanes' primary rays are more coherent than
-    // with a whole 8x8 tile.  The persistent grid has 5120 waves and a tile is the unit they
-    // draw; with too few tiles per wave the last tiles of a launch leave most of the chip idle
-    // (one eighth of a 1080p frame at K = 4: 5.1 ms instead of the ideal 3.1; at K = 16: 3.9).
-    // So K grows with the number of tiles the launch (a rank's shard, not the frame) would have;
-    // each doubling costs some coherence, so it asks for less.  Measured on 1/2, 1/4, 1/8 of the
-    // 1080p frame: best K = 8, 8, 16.  The image does not depend on K (integer accumulation).
-    int k = spp >= 4 ? 4 : (spp >= 2 ? 2 : 1);
-    if (k == 4 && 2 * k <= spp && pixels * 4 / 64 < 100000) k = 8;
+    // with a whole 8x8 tile, and a wave keeps two tiles' accumulators in LDS (the one it hands out
+    // and the one still finishing), which at K = 4 costs the tree-in-LDS kernels a workgroup per CU.
+    // The persistent grid has 5120 waves and a tile is the unit they draw; with too few tiles per
+    // wave the last tiles of a launch leave most of the chip idle.  So K grows with the number of
+    // tiles the launch (a rank's shard, not the frame) would have; each doubling costs some
+    // coherence, so it asks for less.  The image does not depend on K (integer accumulation).
+    int k = spp >= 8 ? 8 : (spp >= 4 ? 4 : (spp >= 2 ? 2 : 1));
     if (k == 8 && 2 * k <= spp && pixels * 8 / 64 < 50000) k = 16;
     while (k < 64 && 2 * k <= spp && pixels * k / 64 < 5120) k *= 2;      // tiny frames: at least a tile per wave
     return k;
@@ -167,6 +166,7 @@ int validate_render(rt_context* ctx, const rt_render_params* p, rt::DRender* rp)
     if (k == 0) k = choose_lanes_per_pixel((long long)p->width * rp->rows, p->spp);
     rp->t_min = p->t_min == 0.0f ? 0.001f : p->t_min;
     rp->flags = p->flags;
+    while (k < 64 && (long long)p->spp * (64 / k) > 0x7fffffffLL) k *= 2;   // a tile's (pixel, sample) units are counted in 32 bits
     rp->lanes_per_pixel = k;
     rp->inv_wm1 = (float)(1.0 / (double)(p->width - 1));
     rp->inv_hm1 = (float)(1.0 / (double)(p->height - 1));

@@ -937,7 +937,7 @@ __device__ __forceinline__ float from_fixed(unsigned long long q) { return (floa
 // (pixel, sample) of the tile are numbered sample-major and handed out dynamically: whenever
 // lanes are free (their path ended) they take the next units, so every trip of the loop traces
 // one ray on all 64 lanes until the tile runs out of samples, whatever the path lengths were.
-// Dynamic LDS: [traversal stack: stack_depth x kBlock ints][accumulators: 4 waves x 3P u64]
+// Dynamic LDS: [traversal stack: stack_depth x kBlock ints][accumulators and pixel tables: 4 waves x 2 tiles x 4P u64]
 // then, for the LDS-resident variant, [nodes][spheres][list positions].
 // MODE: 0 linear scan, 1 BVH, 2 BVH walked in time slices.  Each combination is a kernel of its
 // own: code that a scene never runs (rects, the scan, the tree walk) still costs the code that
@@ -950,10 +950,12 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? RT_WG_PER_CU_SCAN : RT_WG_PER_C
     int* stack = s_dyn + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const int P = 64 / rp.lanes_per_pixel;             // pixels of this wave's tile
-    const int accum_words = 4 * P;                     // per wave: rgb sums per pixel of the tile (3P), then the tile's pixel table
+    // per wave: two tiles in flight (the one whose units are being handed out and the one before
+    // it, whose last paths are still running), each with rgb sums per pixel (3P) and a pixel table (P)
+    const int accum_words = 8 * P;
     unsigned long long* accum = reinterpret_cast<unsigned long long*>(s_dyn + rp.stack_depth * kBlock) + (threadIdx.x >> 6) * accum_words;
-    // pixel table: (x, j) of the tile's q-th pixel, x = -1 where the tile hangs over the image
-    int2* tile_pix = reinterpret_cast<int2*>(accum + 3 * P);
+    // pixel table: (x, j) of the q-th pixel of the two tiles, x = -1 where a tile hangs over the image
+    int2* tile_pix = reinterpret_cast<int2*>(accum + 6 * P);
     const auto geo = stage_geometry<LDS>(sc, s_dyn + rp.stack_depth * kBlock + (kBlock / 64) * accum_words * 2);
     const float4* staged_list = geo.sph;               // the scan reads it when LDS (else it takes the records through scalar loads)
     (void)staged_list;
@@ -977,119 +979,144 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? RT_WG_PER_CU_SCAN : RT_WG_PER_C
     // Persistent waves: the grid is sized to fill the chip once and every wave keeps drawing
     // tiles from one device-wide counter until none are left, so the geometry is staged once per
     // workgroup and light (sky) and heavy tiles balance out across the waves.
+    // Tiles are dealt in eight contiguous bands, one per XCD (each XCD has its own L2, so the rays
+    // of one band keep re-using the BVH nodes that XCD has cached); a wave whose band has run
+    // out helps with the next one.  With the geometry in LDS there is nothing to re-use in L2 and
+    // one band (bottom rows, the heaviest, first) leaves the shortest tail.
     constexpr int kBands = LDS ? 1 : 8;
     int band = LDS ? 0 : (int)(__builtin_amdgcn_s_getreg(6164) & 7u), bands_tried = 0;   // HW_REG_XCC_ID[3:0]
-    for (;;) {
-        // Tiles are dealt in eight contiguous bands, one per XCD (each XCD has its own L2, so the rays
-        // of one band keep re-using the BVH nodes that XCD has cached); a wave whose band has run
-        // out helps with the next one.
-        // With the geometry in LDS there is nothing to re-use in L2 and one band (bottom rows, the
-        // heaviest, first) leaves the shortest tail.
-        unsigned tile = n_tiles;
-        while (bands_tried < kBands) {
-            const unsigned b0 = (unsigned)(((unsigned long long)n_tiles * band) / kBands), b1 = (unsigned)(((unsigned long long)n_tiles * (band + 1)) / kBands);
-            unsigned t = 0u;
-            if (lane == 0) t = atomicAdd(tile_counter + band, 1u);
-            t = (unsigned)__builtin_amdgcn_readfirstlane((int)t);
-            if (b0 + t < b1) { tile = b0 + t; break; }
-            band = (band + 1) % kBands;
-            bands_tried++;
-        }
-        if (tile >= n_tiles) break;
-        const bool wave_ok = true;
-        const int x0 = (int)(tile % (unsigned)tiles_x) * TW, ly0 = (int)(tile / (unsigned)tiles_x) * TH;
+
+    // A wave does not wait for the last paths of a tile before it starts on the next one: the
+    // tile whose units have all been handed out ("older") keeps its accumulators while free lanes
+    // already take units of the next tile ("current") into the other buffer.  All of this state is
+    // wave-uniform.  Only when the current tile runs out as well while the older one still has a
+    // path running (a path longer than a whole tile takes: rare) do free lanes idle.
+    const unsigned tile_units = (rp.max_depth > 0) ? ((unsigned)rp.spp << logP) : 0u;   // < 2^31: the launch picks P for that
+    int cur_buf = 0;                                   // buffer of the current tile; the older tile owns the other one
+    bool cur_valid = false, old_valid = false, more_tiles = true;
+    unsigned cur_tile = 0u, old_tile = 0u;
+    unsigned next = 0u;                                // first unit of the current tile not handed out yet
+
+    // one float4 store per pixel of a finished tile
+    auto write_tile = [&](unsigned tile, int buf) {
+        __builtin_amdgcn_wave_barrier();               // LDS serves one wave's accesses in issue order
         if (lane < P) {
-            accum[lane * 3 + 0] = 0ull; accum[lane * 3 + 1] = 0ull; accum[lane * 3 + 2] = 0ull;
-            const int x = x0 + (lane % TW), ly = ly0 + (lane / TW);
-            const int j = (rp.tile_first + (ly / rp.tile_rows) * rp.tile_step) * rp.tile_rows + (ly % rp.tile_rows);
-            tile_pix[lane] = make_int2((x < rp.width && ly < rp.rows && j < rp.height) ? x : -1, j);
-        }
-        __builtin_amdgcn_wave_barrier();                   // LDS serves one wave's accesses in issue order
-
-        const unsigned long long total = (rp.max_depth > 0) ? ((unsigned long long)rp.spp << logP) : 0ull;
-        unsigned long long next = 0ull;                    // wave-uniform: first unit not handed out yet
-        bool has = false;                                  // this lane is on a path
-        int q = 0, depth = 0;                              // pixel of the tile, rays traced on the path
-        Origin from = no_origin();                         // the primitive the ray starts on
-        V3 o = mk(0, 0, 0), d = mk(0, 0, 1), T = mk(1, 1, 1), L = mk(0, 0, 0);
-        // closest-hit query in progress: candidate so far and traversal position.  cur == kTravDone
-        // on a lane with a path means "ray not started yet".
-        Cand c = no_hit();
-        int cur = kTravDone, sp = 0;
-        for (;;) {
-            if (PROF) tq = clk();
-            const unsigned long long need = __ballot(!has);
-            if (need != 0ull && next < total) {
-                const unsigned long long u = next + (unsigned long long)__builtin_amdgcn_mbcnt_hi((unsigned)(need >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)need, 0u));
-                if (!has && u < total) {
-                    q = (int)(u & (unsigned long long)(P - 1));
-                    const int2 xj = tile_pix[q];
-                    const int x = xj.x, j = xj.y;
-                    if (x >= 0) {
-                        key.pixel = (uint32_t)(j * rp.width + x);
-                        key.sample = (uint32_t)rp.sample_begin + (uint32_t)(u >> logP);
-                        camera_ray(cam, rp, key, x, j, o, d);
-                        T = mk(1.0f, 1.0f, 1.0f);
-                        L = mk(0.0f, 0.0f, 0.0f);
-                        depth = 0;
-                        from = no_origin();
-                        nsamples++;
-                        has = true;
-                    }
-                }
-                next += (unsigned long long)__popcll(need);
-            }
-            if (PROF) { unsigned long long t = clk(); ph[0] += t - tq; tq = t; }
-            if (__ballot(has) == 0ull) {
-                if (next >= total) break;
-                continue;
-            }
-            if (has) {
-                const RayN rn = normalise(d, rp.t_min);
-                // without time slices a query starts and ends inside one trip: its state is local
-                Cand c_trip = no_hit();
-                int cur_trip = kTravDone, sp_trip = 0;
-                Cand& cq = *(SLICED ? &c : &c_trip);
-                int& curq = *(SLICED ? &cur : &cur_trip);
-                int& spq = *(SLICED ? &sp : &sp_trip);
-                if (curq == kTravDone) {                   // a new ray: always-tested primitives first
-                    cq = no_hit();
-                    hit_always<COUNT, RECTS>(sc, o, d, rn, rp.t_min, from, cq, cn);
-                    nrays++;
-                    depth++;
-                    if constexpr (!BVH) hit_list<COUNT, LDS>(sc, staged_list, o, rn, from, cq, cn);
-                    else if (sc.root != kNoBvh) { hit_own_sphere(geo, o, rn, from, cq); curq = geo.root_ref(sc.root); spq = 0; }
-                }
-                if (PROF) { unsigned long long t = clk(); ph[1] += t - tq; tq = t; }
-                if constexpr (BVH)
-                    if (curq != kTravDone) hit_bvh<COUNT, SLICED>(geo, o, rn, from, stack, rp.slice, rp.leaf_quorum, curq, spq, cq, cn);
-                if (PROF) { unsigned long long t = clk(); ph[2] += t - tq; tq = t; }
-                if (curq == kTravDone) {                   // query finished (else: resumed next trip)
-                    if (shade<COUNT, RECTS>(sc, geo, rp, cq, key, depth, refine, rn, o, d, T, L, from, cn)) {
-                        atomicAdd(&accum[q * 3 + 0], to_fixed(L.x));
-                        atomicAdd(&accum[q * 3 + 1], to_fixed(L.y));
-                        atomicAdd(&accum[q * 3 + 2], to_fixed(L.z));
-                        has = false;
-                    }
-                }
-                if (PROF) { unsigned long long t = clk(); ph[4] += t - tq; tq = t; }
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-
-        // one float4 store per pixel of the tile
-        if (wave_ok && lane < P) {
-            const int x = x0 + (lane % TW), ly = ly0 + (lane / TW);
+            const int x = (int)(tile % (unsigned)tiles_x) * TW + (lane % TW), ly = (int)(tile / (unsigned)tiles_x) * TH + (lane / TW);
             const int j = (rp.tile_first + (ly / rp.tile_rows) * rp.tile_step) * rp.tile_rows + (ly % rp.tile_rows);
             if (x < rp.width && ly < rp.rows && j < rp.height) {
+                const unsigned long long* acc = accum + (buf * P + lane) * 3;
                 float a = (float)rp.spp;
-                V3 total_rgb = mk(from_fixed(accum[lane * 3 + 0]), from_fixed(accum[lane * 3 + 1]), from_fixed(accum[lane * 3 + 2]));
+                V3 total_rgb = mk(from_fixed(acc[0]), from_fixed(acc[1]), from_fixed(acc[2]));
                 if (rp.flags & 1u) total_rgb = (1.0f / a) * total_rgb;
                 out[(size_t)ly * rp.width + x] = make_float4(total_rgb.x, total_rgb.y, total_rgb.z, a);
             }
         }
         __builtin_amdgcn_wave_barrier();
-    }  // next tile
+    };
+
+    bool has = false;                                  // this lane is on a path
+    int q = 0, depth = 0;                              // pixel slot (buffer * P + pixel of the tile), rays traced on the path
+    Origin from = no_origin();                         // the primitive the ray starts on
+    V3 o = mk(0, 0, 0), d = mk(0, 0, 1), T = mk(1, 1, 1), L = mk(0, 0, 0);
+    // closest-hit query in progress: candidate so far and traversal position.  cur == kTravDone
+    // on a lane with a path means "ray not started yet".
+    Cand c = no_hit();
+    int cur = kTravDone, sp = 0;
+    for (;;) {
+        if (PROF) tq = clk();
+        // the older tile's last path has ended: write its pixels
+        if (old_valid && __ballot(has && (q >> logP) != cur_buf) == 0ull) {
+            write_tile(old_tile, cur_buf ^ 1);
+            old_valid = false;
+        }
+        // every unit of the current tile is handed out: it becomes the older tile
+        if (cur_valid && next >= tile_units && !old_valid) {
+            old_tile = cur_tile; old_valid = true;
+            cur_buf ^= 1; cur_valid = false;
+        }
+        if (!cur_valid && more_tiles) {                    // draw a tile into the free buffer
+            unsigned tile = n_tiles;
+            while (bands_tried < kBands) {
+                const unsigned b0 = (unsigned)(((unsigned long long)n_tiles * band) / kBands), b1 = (unsigned)(((unsigned long long)n_tiles * (band + 1)) / kBands);
+                unsigned t = 0u;
+                if (lane == 0) t = atomicAdd(tile_counter + band, 1u);
+                t = (unsigned)__builtin_amdgcn_readfirstlane((int)t);
+                if (b0 + t < b1) { tile = b0 + t; break; }
+                band = (band + 1) % kBands;
+                bands_tried++;
+            }
+            if (tile >= n_tiles) more_tiles = false;
+            else {
+                cur_tile = tile; cur_valid = true; next = 0u;
+                if (lane < P) {
+                    const int slot = cur_buf * P + lane;
+                    accum[slot * 3 + 0] = 0ull; accum[slot * 3 + 1] = 0ull; accum[slot * 3 + 2] = 0ull;
+                    const int x = (int)(tile % (unsigned)tiles_x) * TW + (lane % TW), ly = (int)(tile / (unsigned)tiles_x) * TH + (lane / TW);
+                    const int j = (rp.tile_first + (ly / rp.tile_rows) * rp.tile_step) * rp.tile_rows + (ly % rp.tile_rows);
+                    tile_pix[slot] = make_int2((x < rp.width && ly < rp.rows && j < rp.height) ? x : -1, j);
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        const unsigned long long need = __ballot(!has);
+        if (need != 0ull && cur_valid && next < tile_units) {
+            const unsigned u = next + __builtin_amdgcn_mbcnt_hi((unsigned)(need >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)need, 0u));
+            if (!has && u < tile_units) {
+                q = (int)(u & (unsigned)(P - 1)) + (cur_buf << logP);
+                const int2 xj = tile_pix[q];
+                const int x = xj.x, j = xj.y;
+                if (x >= 0) {
+                    key.pixel = (uint32_t)(j * rp.width + x);
+                    key.sample = (uint32_t)rp.sample_begin + (uint32_t)(u >> logP);
+                    camera_ray(cam, rp, key, x, j, o, d);
+                    T = mk(1.0f, 1.0f, 1.0f);
+                    L = mk(0.0f, 0.0f, 0.0f);
+                    depth = 0;
+                    from = no_origin();
+                    nsamples++;
+                    has = true;
+                }
+            }
+            next += (unsigned)__popcll(need);
+        }
+        if (PROF) { unsigned long long t = clk(); ph[0] += t - tq; tq = t; }
+        if (__ballot(has) == 0ull) {
+            // nothing in flight: either more units or tiles follow (each trip then hands out units,
+            // retires a tile or draws one), or the wave is done
+            if (!cur_valid && !old_valid && !more_tiles) break;
+            continue;
+        }
+        if (has) {
+            const RayN rn = normalise(d, rp.t_min);
+            // without time slices a query starts and ends inside one trip: its state is local
+            Cand c_trip = no_hit();
+            int cur_trip = kTravDone, sp_trip = 0;
+            Cand& cq = *(SLICED ? &c : &c_trip);
+            int& curq = *(SLICED ? &cur : &cur_trip);
+            int& spq = *(SLICED ? &sp : &sp_trip);
+            if (curq == kTravDone) {                   // a new ray: always-tested primitives first
+                cq = no_hit();
+                hit_always<COUNT, RECTS>(sc, o, d, rn, rp.t_min, from, cq, cn);
+                nrays++;
+                depth++;
+                if constexpr (!BVH) hit_list<COUNT, LDS>(sc, staged_list, o, rn, from, cq, cn);
+                else if (sc.root != kNoBvh) { hit_own_sphere(geo, o, rn, from, cq); curq = geo.root_ref(sc.root); spq = 0; }
+            }
+            if (PROF) { unsigned long long t = clk(); ph[1] += t - tq; tq = t; }
+            if constexpr (BVH)
+                if (curq != kTravDone) hit_bvh<COUNT, SLICED>(geo, o, rn, from, stack, rp.slice, rp.leaf_quorum, curq, spq, cq, cn);
+            if (PROF) { unsigned long long t = clk(); ph[2] += t - tq; tq = t; }
+            if (curq == kTravDone) {                   // query finished (else: resumed next trip)
+                if (shade<COUNT, RECTS>(sc, geo, rp, cq, key, depth, refine, rn, o, d, T, L, from, cn)) {
+                    atomicAdd(&accum[q * 3 + 0], to_fixed(L.x));
+                    atomicAdd(&accum[q * 3 + 1], to_fixed(L.y));
+                    atomicAdd(&accum[q * 3 + 2], to_fixed(L.z));
+                    has = false;
+                }
+            }
+            if (PROF) { unsigned long long t = clk(); ph[4] += t - tq; tq = t; }
+        }
+    }
 
     unsigned long long r_all = wave_sum(nrays), s_all = wave_sum(nsamples);
     if (lane == 0 && r_all) {
@@ -1174,7 +1201,7 @@ hipError_t launch_render(const DScene& sc, const DCamera& cam, const DRender& rp
     // and the sphere list
     DRender r = rp;
     r.stack_depth = sc.use_bvh ? sc.bvh_depth + 1 : 1;   // one push per inner level at most
-    size_t lds = (size_t)r.stack_depth * kBlock * sizeof(int) + (size_t)(kBlock / 64) * 4 * (64 / rp.lanes_per_pixel) * sizeof(unsigned long long);
+    size_t lds = (size_t)r.stack_depth * kBlock * sizeof(int) + (size_t)(kBlock / 64) * 8 * (64 / rp.lanes_per_pixel) * sizeof(unsigned long long);
     const size_t geo_bytes = (size_t)sc.n_nodes * 64 + (size_t)sc.n_sph_padded * 20;
     // the tree walk keeps tree and spheres in LDS up to 40 KB per workgroup.  The scan reads a
     // short list (a room with a few balls) from LDS: 6 % faster than through scalar loads, whose

@@ -100,6 +100,31 @@ def test_determinism_tiles_and_sample_windows(ctx, api):
     assert rmse < 2e-3
 
 
+def test_tiles_that_turn_over_faster_than_paths_end(ctx, api, oracle, rtiow_flat):
+    """A wave starts on its next tile while the last paths of the one before still run.  With one
+    to five samples per pixel a tile's units are handed out in one or two trips, so tiles turn
+    over far faster than the long (glass, 50-bounce) paths end: every tile shape gives the same
+    bits and the same ray count, ragged frames included, and the image stays within the
+    keyed-stream bound of the CPU restatement (most pixels equal to rounding)."""
+    P = api.Context.params
+    cd = oracle.camera(**CAM)
+    for (W, H, spp) in ((67, 45, 1), (130, 9, 3), (9, 130, 2), (2, 2, 5), (64, 2, 1)):
+        want, rays = None, None
+        for k in (1, 2, 4, 8, 16, 32, 64):
+            got = ctx.render_host(P(W, H, spp, 50, 31, lanes_per_pixel=k))
+            st = ctx.stats()
+            assert st["samples"] == W * H * spp
+            if want is None:
+                want, rays = got, st["rays"]
+                sums, n_rays = oracle.render(rtiow_flat, cd, W, H, spp, 50, 31, threads=8)
+                close = np.all(np.abs(sums / spp - got[..., :3].astype(np.float64) / spp) < 1e-5, axis=-1)
+                assert close.mean() > 0.97, close.mean()
+                # a path that crosses a float-vs-double branch threshold runs on for up to 49 rays more or fewer
+                assert abs(rays - n_rays) <= 100 + n_rays // 2000
+            assert np.array_equal(got, want), (W, H, spp, k)
+            assert st["rays"] == rays
+
+
 def test_depth_limits(ctx, api):
     P = api.Context.params
     black = ctx.render_host(P(64, 48, 4, 0, 9))
