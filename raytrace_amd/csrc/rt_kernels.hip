@@ -937,7 +937,7 @@ __device__ __forceinline__ float from_fixed(unsigned long long q) { return (floa
 // (pixel, sample) of the tile are numbered sample-major and handed out dynamically: whenever
 // lanes are free (their path ended) they take the next units, so every trip of the loop traces
 // one ray on all 64 lanes until the tile runs out of samples, whatever the path lengths were.
-// Dynamic LDS: [traversal stack: stack_depth x kBlock ints][accumulators and pixel tables: 4 waves x 2 tiles x 4P u64]
+// Dynamic LDS: [traversal stack: stack_depth x kBlock ints][accumulators and pixel tables: 4 waves x (8P + 1) u64]
 // then, for the LDS-resident variant, [nodes][spheres][list positions].
 // MODE: 0 linear scan, 1 BVH, 2 BVH walked in time slices.  Each combination is a kernel of its
 // own: code that a scene never runs (rects, the scan, the tree walk) still costs the code that
@@ -951,11 +951,13 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? RT_WG_PER_CU_SCAN : RT_WG_PER_C
     const int lane = threadIdx.x & 63;
     const int P = 64 / rp.lanes_per_pixel;             // pixels of this wave's tile
     // per wave: two tiles in flight (the one whose units are being handed out and the one before
-    // it, whose last paths are still running), each with rgb sums per pixel (3P) and a pixel table (P)
-    const int accum_words = 8 * P;
+    // it, whose last paths are still running), each with rgb sums per pixel (3P), a pixel table (P)
+    // and the tile's first row in the framebuffer (an int)
+    const int accum_words = 8 * P + 1;
     unsigned long long* accum = reinterpret_cast<unsigned long long*>(s_dyn + rp.stack_depth * kBlock) + (threadIdx.x >> 6) * accum_words;
     // pixel table: (x, j) of the q-th pixel of the two tiles, x = -1 where a tile hangs over the image
     int2* tile_pix = reinterpret_cast<int2*>(accum + 6 * P);
+    int* tile_row = reinterpret_cast<int*>(accum + 8 * P);   // first framebuffer row of the two tiles
     const auto geo = stage_geometry<LDS>(sc, s_dyn + rp.stack_depth * kBlock + (kBlock / 64) * accum_words * 2);
     const float4* staged_list = geo.sph;               // the scan reads it when LDS (else it takes the records through scalar loads)
     (void)staged_list;
@@ -994,21 +996,19 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? RT_WG_PER_CU_SCAN : RT_WG_PER_C
     const unsigned tile_units = (rp.max_depth > 0) ? ((unsigned)rp.spp << logP) : 0u;   // < 2^31: the launch picks P for that
     int cur_buf = 0;                                   // buffer of the current tile; the older tile owns the other one
     bool cur_valid = false, old_valid = false, more_tiles = true;
-    unsigned cur_tile = 0u, old_tile = 0u;
     unsigned next = 0u;                                // first unit of the current tile not handed out yet
 
     // one float4 store per pixel of a finished tile
-    auto write_tile = [&](unsigned tile, int buf) {
+    auto write_tile = [&](int buf) {
         __builtin_amdgcn_wave_barrier();               // LDS serves one wave's accesses in issue order
         if (lane < P) {
-            const int x = (int)(tile % (unsigned)tiles_x) * TW + (lane % TW), ly = (int)(tile / (unsigned)tiles_x) * TH + (lane / TW);
-            const int j = (rp.tile_first + (ly / rp.tile_rows) * rp.tile_step) * rp.tile_rows + (ly % rp.tile_rows);
-            if (x < rp.width && ly < rp.rows && j < rp.height) {
-                const unsigned long long* acc = accum + (buf * P + lane) * 3;
+            const int slot = buf * P + lane;
+            if (tile_pix[slot].x >= 0) {
+                const unsigned long long* acc = accum + slot * 3;
                 float a = (float)rp.spp;
                 V3 total_rgb = mk(from_fixed(acc[0]), from_fixed(acc[1]), from_fixed(acc[2]));
                 if (rp.flags & 1u) total_rgb = (1.0f / a) * total_rgb;
-                out[(size_t)ly * rp.width + x] = make_float4(total_rgb.x, total_rgb.y, total_rgb.z, a);
+                out[(size_t)(tile_row[buf] + lane / TW) * rp.width + tile_pix[slot].x] = make_float4(total_rgb.x, total_rgb.y, total_rgb.z, a);
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -1026,12 +1026,12 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? RT_WG_PER_CU_SCAN : RT_WG_PER_C
         if (PROF) tq = clk();
         // the older tile's last path has ended: write its pixels
         if (old_valid && __ballot(has && (q >> logP) != cur_buf) == 0ull) {
-            write_tile(old_tile, cur_buf ^ 1);
+            write_tile(cur_buf ^ 1);
             old_valid = false;
         }
         // every unit of the current tile is handed out: it becomes the older tile
         if (cur_valid && next >= tile_units && !old_valid) {
-            old_tile = cur_tile; old_valid = true;
+            old_valid = true;
             cur_buf ^= 1; cur_valid = false;
         }
         if (!cur_valid && more_tiles) {                    // draw a tile into the free buffer
@@ -1047,13 +1047,14 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? RT_WG_PER_CU_SCAN : RT_WG_PER_C
             }
             if (tile >= n_tiles) more_tiles = false;
             else {
-                cur_tile = tile; cur_valid = true; next = 0u;
+                cur_valid = true; next = 0u;
                 if (lane < P) {
                     const int slot = cur_buf * P + lane;
                     accum[slot * 3 + 0] = 0ull; accum[slot * 3 + 1] = 0ull; accum[slot * 3 + 2] = 0ull;
                     const int x = (int)(tile % (unsigned)tiles_x) * TW + (lane % TW), ly = (int)(tile / (unsigned)tiles_x) * TH + (lane / TW);
                     const int j = (rp.tile_first + (ly / rp.tile_rows) * rp.tile_step) * rp.tile_rows + (ly % rp.tile_rows);
                     tile_pix[slot] = make_int2((x < rp.width && ly < rp.rows && j < rp.height) ? x : -1, j);
+                    if (lane == 0) tile_row[cur_buf] = ly;
                 }
                 __builtin_amdgcn_wave_barrier();
             }
@@ -1201,7 +1202,7 @@ hipError_t launch_render(const DScene& sc, const DCamera& cam, const DRender& rp
     // and the sphere list
     DRender r = rp;
     r.stack_depth = sc.use_bvh ? sc.bvh_depth + 1 : 1;   // one push per inner level at most
-    size_t lds = (size_t)r.stack_depth * kBlock * sizeof(int) + (size_t)(kBlock / 64) * 8 * (64 / rp.lanes_per_pixel) * sizeof(unsigned long long);
+    size_t lds = (size_t)r.stack_depth * kBlock * sizeof(int) + (size_t)(kBlock / 64) * (8 * (64 / rp.lanes_per_pixel) + 1) * sizeof(unsigned long long);
     const size_t geo_bytes = (size_t)sc.n_nodes * 64 + (size_t)sc.n_sph_padded * 20;
     // the tree walk keeps tree and spheres in LDS up to 40 KB per workgroup.  The scan reads a
     // short list (a room with a few balls) from LDS: 6 % faster than through scalar loads, whose
