@@ -125,6 +125,33 @@ def test_tiles_that_turn_over_faster_than_paths_end(ctx, api, oracle, rtiow_flat
             assert st["rays"] == rays
 
 
+def test_frames_overlapping_on_two_streams(api, rtiow_flat):
+    """A frame sequence alternates between two contexts on two streams, so a frame starts while the
+    one before it still runs (bench.py does this): every frame has the bits it has alone."""
+    import torch
+    P = api.Context.params
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    ctxs = []
+    for s in streams:
+        c = api.Context(0)
+        c.set_stream(s.cuda_stream)
+        c.upload_scene(rtiow_flat)
+        c.set_camera(**CAM)
+        ctxs.append(c)
+    W, H, spp, n = 240, 160, 24, 6
+    bufs = [torch.zeros((H, W, 4), dtype=torch.float32, device="cuda") for _ in range(n)]
+    torch.cuda.synchronize()
+    for k in range(n):                                  # queued back to back, nothing waits in between
+        ctxs[k & 1].render(P(W, H, spp, 50, 100 + k), bufs[k].data_ptr())
+    torch.cuda.synchronize()
+    got = [b.cpu().numpy() for b in bufs]
+    for k in range(n):
+        alone = ctxs[0].render_host(P(W, H, spp, 50, 100 + k))
+        assert np.array_equal(got[k], alone), k
+    for c in ctxs:
+        c.close()
+
+
 def test_depth_limits(ctx, api):
     P = api.Context.params
     black = ctx.render_host(P(64, 48, 4, 0, 9))
