@@ -14,6 +14,13 @@ def run(label, W, H, spp, K=0):
     for _ in range(3):
         c.render(api.Context.params(W, H, spp, 50, 1, lanes_per_pixel=K), buf.data_ptr()); st = c.stats(); ms.append(st["kernel_ms"])
     print("%%s %%s: %%.2f ms %%.0f Mrays/s" %% (os.environ["VARIANT"], label, min(ms), st["rays"] / min(ms) / 1e3), flush=True)
+if os.environ.get("RT_PROBE") == "c4":
+    c.upload_scene(S.stress_flat(1000000), accel=api.RT_ACCEL_BVH); c.set_camera(**S.stress_camera(aspect).desc())
+    run("C4@16", 3840, 2160, 16)
+    run("C4@64", 3840, 2160, 64)
+    c.upload_scene(S.stress_flat(100000), accel=api.RT_ACCEL_BVH)
+    run("10^5 spheres 1080p@64", 1920, 1080, 64)
+    sys.exit(0)
 c.upload_scene(S.flatten(S.rtiow_scene())); c.set_camera(**S.rtiow_camera(aspect).desc())
 for K in (4, 8):
     run("C2 K%%d" %% K, 1920, 1080, 100, K)
