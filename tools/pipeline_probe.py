@@ -16,8 +16,9 @@ for s in streams:
 bufs = [torch.zeros((1080, 1920, 4), dtype=torch.float32, device="cuda") for _ in range(2)]
 torch.cuda.synchronize()
 N = 40
-for world in (1, 2, 4, 8):
-    p = api.Context.params(1920, 1080, 100, 50, 1, tiles=(4, 0, world) if world > 1 else (0, 0, 0))
+KS = [int(k) for k in os.environ.get("RT_PROBE_K", "0").split(",")]
+for world, K in [(w, k) for w in (1, 2, 4, 8) for k in KS]:
+    p = api.Context.params(1920, 1080, 100, 50, 1, tiles=(4, 0, world) if world > 1 else (0, 0, 0), lanes_per_pixel=K)
     for mode in ("one stream", "two streams"):
         for rep in range(2):
             torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -25,6 +26,6 @@ for world in (1, 2, 4, 8):
                 i = (k & 1) if mode == "two streams" else 0
                 ctxs[i].render(p, bufs[i].data_ptr())
             torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / N * 1e3
-        print(f"world {world} {mode}: {dt:.3f} ms/frame", flush=True)
+        print(f"world {world} K={K} {mode}: {dt:.3f} ms/frame", flush=True)
 ref = bufs[0].clone()
 print("same bits on both streams:", bool(torch.equal(bufs[0], bufs[1])))
