@@ -121,7 +121,7 @@ int shard_rows(int height, int tile_rows, int tile_first, int tile_step) {
 }
 
 int choose_lanes_per_pixel(long long pixels, int spp) {
-    // A wave's tile holds 64/K pixels.  K = 8 (an 8x1 tile, eight samples of a pixel in flight at
+    // A wave's tile holds 64/K pixels.  K = 8 (a 4x2 tile, eight samples of a pixel in flight at
     // once) measured best on whole 1080p frames: the lanes' primary rays are more coherent than
     // with a whole 8x8 tile, and a wave keeps two tiles' accumulators in LDS (the one it hands out
     // and the one still finishing), which at K = 4 costs the tree-in-LDS kernels a workgroup per CU.
