@@ -49,7 +49,7 @@ if main:
         "fetch_correction": "x2 (gfx950 FETCH_SIZE tallies 128-B requests at 64 B); immaterial next to the writes",
         "hbm_bytes_per_launch": int(fetch_kb * 1024 * 2 + write_kb * 1024),
         "algorithmic_bytes_per_launch": 1920 * 1080 * 16,
-        "note": "framebuffer float4 stores in 128-B row segments of the 8x1 wave tile; the scene (30 KB) is "
+        "note": "framebuffer float4 stores in 64-B row segments of the 4x2 wave tile; the scene (30 KB) is "
                 "read once per workgroup into LDS",
     }
     with open(os.path.join(dst, "hbm_traffic.json"), "w") as f:
