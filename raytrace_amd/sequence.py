@@ -46,26 +46,31 @@ def frame_path(out_dir: str, frame: int, fmt: str, quality: str = "low") -> str:
 
 def render_sequence(ctx, cam: S.camera, frames, width: int, height: int, spp: int, out_dir: str | None,
                     max_depth: int = 25, seed: int = 1, fmt: str = "p3", quality: str = "low",
-                    rank: int = 0, world: int = 1, first_frame: int = 0):
+                    rank: int = 0, world: int = 1, first_frame: int = 0, overlap_ctx=None):
     """Renders frames first_frame .. first_frame+frames-1 of the camera path that starts at `cam`.
     Every rank advances the camera through all frames (cheap, host) and renders those with
-    frame % world == rank.  Returns [(frame, rays, kernel_ms)] of the frames this rank rendered."""
+    frame % world == rank.  Returns [(frame, rays, kernel_ms)] of the frames this rank rendered.
+
+    overlap_ctx: a second context holding the same scene.  Frames then alternate between the two
+    contexts and a frame is launched before the one before it is read back and written, so the
+    GPU renders while the host formats the file (P3 text takes longer to write than a frame takes
+    to render); with the contexts on two streams the frame also starts in the tail of the one
+    before it.  The files are the same either way."""
     import torch
 
     from . import api
 
-    fb = torch.zeros((height, width, 4), dtype=torch.float32, device=f"cuda:{ctx.device}")
-    rgb8 = torch.zeros((height, width, 3), dtype=torch.uint8, device=f"cuda:{ctx.device}")
+    if fmt not in ("p3", "p6", "png"):
+        raise ValueError(f"unknown format {fmt!r}")
+    ctxs = [ctx] if overlap_ctx is None else [ctx, overlap_ctx]
+    fbs = [torch.zeros((height, width, 4), dtype=torch.float32, device=f"cuda:{c.device}") for c in ctxs]
+    rgbs = [torch.zeros((height, width, 3), dtype=torch.uint8, device=f"cuda:{c.device}") for c in ctxs]
+    torch.cuda.synchronize()                                    # the buffers are zeroed on torch's stream
     done = []
-    for frame in range(first_frame + frames):
-        S.update_scene(cam, frame)                              # cuda/main.cu:564
-        if frame < first_frame or frame % world != rank:
-            continue
-        ctx.set_camera(**cam.desc())
-        ctx.render(api.Context.params(width, height, spp, max_depth, seed=seed + frame), fb.data_ptr())
-        ctx.quantize(fb.data_ptr(), width * height, spp, rgb8.data_ptr())
-        st = ctx.stats()
-        img = rgb8.cpu().numpy()
+
+    def finish(frame, slot):
+        st = ctxs[slot].stats()                                 # waits for that context's stream
+        img = rgbs[slot].cpu().numpy()
         if out_dir is not None:
             path = frame_path(out_dir, frame, fmt, quality)
             os.makedirs(os.path.dirname(path), exist_ok=True)
@@ -73,12 +78,30 @@ def render_sequence(ctx, cam: S.camera, frames, width: int, height: int, spp: in
                 ppm.write_p3(path, img)
             elif fmt == "p6":
                 ppm.write_p6(path, img)
-            elif fmt == "png":
+            else:
                 with open(path, "wb") as f:
                     f.write(png_bytes(img))
-            else:
-                raise ValueError(f"unknown format {fmt!r}")
         done.append((frame, st["rays"], st["kernel_ms"]))
+
+    pending, launched = None, 0
+    for frame in range(first_frame + frames):
+        S.update_scene(cam, frame)                              # cuda/main.cu:564
+        if frame < first_frame or frame % world != rank:
+            continue
+        slot = launched % len(ctxs)
+        launched += 1
+        c = ctxs[slot]
+        c.set_camera(**cam.desc())
+        c.render(api.Context.params(width, height, spp, max_depth, seed=seed + frame), fbs[slot].data_ptr())
+        c.quantize(fbs[slot].data_ptr(), width * height, spp, rgbs[slot].data_ptr())
+        if pending is not None:
+            finish(*pending)
+        pending = (frame, slot)
+        if len(ctxs) == 1:
+            finish(*pending)
+            pending = None
+    if pending is not None:
+        finish(*pending)
     return done
 
 

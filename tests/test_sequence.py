@@ -53,4 +53,17 @@ def test_sequence_frames_on_gpu(tmp_path, oracle):
     img = ctx.render_host(api.Context.params(W, H, spp, 25, seed=1 + 2))
     want = oracle.write_color(img[..., :3].astype(np.float64).reshape(-1, 3), spp).reshape(H, W, 3)[::-1]
     assert np.array_equal(p3, want.astype(np.uint8))
+    # two contexts on two streams, a frame launched before the one before it is written: same files
+    import torch
+    other = api.Context(0)
+    stream = torch.cuda.Stream()
+    other.set_stream(stream.cuda_stream)
+    other.upload_scene(S.flatten(S.rtiow_scene()))
+    cam4 = S.rtiow_camera(W / H)
+    out2 = tmp_path / "overlapped"
+    done3 = sequence.render_sequence(ctx, cam4, 3, W, H, spp, str(out2), fmt="p3", overlap_ctx=other)
+    assert [(d[0], d[1]) for d in done3] == [(d[0], d[1]) for d in done]
+    for f in range(3):
+        assert open(sequence.frame_path(str(out2), f, "p3")).read() == open(sequence.frame_path(str(tmp_path), f, "p3")).read()
+    other.close()
     ctx.close()

@@ -51,17 +51,17 @@ print("C4 per ray:", {k: round(cst[k] / cst["rays"], 2) for k in ("box_tests", "
 # C5: camera path, 1080p frames of the RTIOW scene, yaw +-0.125 deg/frame (cuda/main.cu:227-238)
 ctx.upload_scene(S.flatten(S.rtiow_scene()))
 cam = S.rtiow_camera(aspect)
-buf = torch.zeros((1080, 1920, 4), dtype=torch.float32, device="cuda")
-rgb8 = torch.zeros((1080, 1920, 3), dtype=torch.uint8, device="cuda")
 frames = int(os.environ.get("C5_FRAMES", "8")); spp = int(os.environ.get("C5_SPP", "256"))
-torch.cuda.synchronize(); t0 = time.time(); rays = 0
-for f in range(frames):
-    S.update_scene(cam, f)
-    ctx.set_camera(**cam.desc())
-    ctx.render(P(1920, 1080, spp, 50, seed=1000 + f), buf.data_ptr())
-    ctx.quantize(buf.data_ptr(), 1920 * 1080, spp, rgb8.data_ptr())
-    host = rgb8.cpu()
-    rays += ctx.stats()["rays"]
+# the driver of raytrace_amd/sequence.py with a second context on a second stream: a frame is
+# launched before the one before it is read back (out_dir=None: no files)
+from raytrace_amd import sequence
+other = api.Context(0)
+side = torch.cuda.Stream()
+other.set_stream(side.cuda_stream)
+other.upload_scene(S.flatten(S.rtiow_scene()))
+torch.cuda.synchronize(); t0 = time.time()
+done = sequence.render_sequence(ctx, cam, frames, 1920, 1080, spp, None, max_depth=50, seed=1000, overlap_ctx=other)
+rays = sum(d[1] for d in done)
 dt = time.time() - t0
 out["C5_camera_path"] = dict(frames=frames, spp=spp, s_per_frame=dt / frames, mrays_s=rays / dt / 1e6,
                              s_for_240_frames=dt / frames * 240)
