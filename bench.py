@@ -142,9 +142,14 @@ def main():
     # Two frames in flight: frame k+1 is launched on a second stream (its own context, counters
     # and framebuffer) before frame k is gathered, so it starts in the tail of frame k, where the
     # last long paths leave most of the chip idle, and renders while frame k's shards travel.
-    # The gather itself stays on torch's current stream.
+    # The gather itself stays on torch's current stream.  There are three framebuffers for the
+    # two contexts: the gather of frame k finds room on the chip only in the tail of frame k+1
+    # (its kernels wait for workgroup slots like any other), and with a third buffer frame k+2
+    # does not wait for it.
+    n_ctx = args.frames_in_flight
+    n_buf = 3 if n_ctx == 2 else 1
     main = torch.cuda.current_stream()
-    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    streams = [torch.cuda.Stream() for _ in range(n_ctx)]
     aspect = float(np.float32(W / H))
     flat = S.flatten(S.rtiow_scene())
     ctxs = []
@@ -158,27 +163,27 @@ def main():
 
     tiles = (TILE_ROWS, rank, world) if world > 1 else (0, 0, 0)
     max_rows = rdist.max_shard_rows(H, TILE_ROWS, world) if world > 1 else H
-    shards = [torch.zeros((max_rows, W, 4), dtype=torch.float32, device="cuda") for _ in streams]
+    shards = [torch.zeros((max_rows, W, 4), dtype=torch.float32, device="cuda") for _ in range(n_buf)]
     shard = shards[0]
     params = api.Context.params(W, H, SPP, DEPTH, SEED, tiles=tiles)
-    rendered = [torch.cuda.Event(), torch.cuda.Event()]      # frame in buffer i is complete
-    consumed = [torch.cuda.Event(), torch.cuda.Event()]      # buffer i has been gathered and may be overwritten
+    rendered = [torch.cuda.Event() for _ in range(n_buf)]    # the frame in buffer i is complete
+    consumed = [torch.cuda.Event() for _ in range(n_buf)]    # buffer i has been gathered and may be overwritten
     torch.cuda.synchronize()
-    for i, s in enumerate(streams):
+    for i in range(n_buf):
         consumed[i].record(main)
 
     def launch(k, ev=None):
-        i = k & 1 if args.frames_in_flight == 2 else 0
-        streams[i].wait_event(consumed[i])
+        c, i = k % n_ctx, k % n_buf                          # launches of one context run in stream order
+        streams[c].wait_event(consumed[i])
         if ev:
-            ev[0].record(streams[i])
-        ctxs[i].render(params, shards[i].data_ptr())
+            ev[0].record(streams[c])
+        ctxs[c].render(params, shards[i].data_ptr())
         if ev:
-            ev[1].record(streams[i])
-        rendered[i].record(streams[i])
+            ev[1].record(streams[c])
+        rendered[i].record(streams[c])
 
     def collect(k):
-        i = k & 1 if args.frames_in_flight == 2 else 0
+        i = k % n_buf
         main.wait_event(rendered[i])
         if args.backend == "gloo" and world > 1:
             frame = rdist.gather_frame(shards[i].cpu(), H, TILE_ROWS, rank, world)
@@ -188,15 +193,12 @@ def main():
         return frame
 
     def run(n, events=None):
-        frame = None
-        if n > 0:
-            launch(0, events[0] if events else None)
+        frame, launched = None, 0
         for k in range(n):
-            if k + 1 < n and args.frames_in_flight == 2:
-                launch(k + 1, events[k + 1] if events else None)
+            while launched < n and launched < k + n_buf:     # up to n_buf - 1 frames ahead of the gather
+                launch(launched, events[launched] if events else None)
+                launched += 1
             frame = collect(k)
-            if k + 1 < n and args.frames_in_flight == 1:
-                launch(k + 1, events[k + 1] if events else None)
         return frame
 
     def fence():
