@@ -16,7 +16,7 @@ def test_two_ranks_assemble_the_single_gpu_frame():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", "29517", os.path.join(ROOT, "bench.py"),
-           "--gpus", "2", "--steps", "3", "--warmup", "1", "--backend", "gloo", "--check"]   # three steps: two frames in flight, both buffers reused
+           "--gpus", "2", "--steps", "5", "--warmup", "1", "--backend", "gloo", "--check"]   # five steps: two frames in flight, all three buffers reused
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
