@@ -5,7 +5,7 @@
 A step is one frame.  With N > 1 (one process per GPU, launched by torch.distributed.run) the
 frame is split into interleaved 4-row tiles, each rank renders its tiles and the partial
 framebuffers are gathered on rank 0 over RCCL, inside the timed region.  Two frames are in flight:
-frame k+1 is launched (second stream, second framebuffer) before frame k is gathered, so the
+frame k+1 is launched (second stream, its own framebuffer) before frame k is gathered, so the
 timed K steps are K complete frames, rendered and gathered, at the throughput a frame sequence
 gets; the time of one launch from start to end is reported beside it (roofline.kernel_ms).
 A ray is one closest-hit query (main.cc:18), counted on the device.
