@@ -15,7 +15,7 @@
  *   init_render + render<<<>>>   cuda/main.cu:281-355,582  rt_render / rt_render_host
  *   pixel/sample loop, ray_color main.cc:10-35,111-126     rt_render / rt_render_host
  *   world.hit (closest hit)      main.cc:18,
- *                                sceneobject_list.h:26-39  rt_trace_primary
+ *                                sceneobject_list.h:26-39  rt_trace_primary (+ rt_trace_primary_noalloc)
  *   write_color / output_image   color.h:9-26,
  *                                cuda/main.cu:358-383      rt_quantize
  *   gpuErrchk                    cuda/main.cu:24-32        return codes + rt_last_error
@@ -169,6 +169,18 @@ int rt_render_host(rt_context* ctx, const rt_render_params* params, float* rgba_
 
 /* Closest hit of n explicit rays (host arrays; rays = n x (ox oy oz dx dy dz)). */
 int rt_trace_primary(rt_context* ctx, const float* rays_host, int32_t n, float t_min, rt_hit* hits_host);
+
+/* rt_trace_primary for callers that cannot allocate device memory: tight serving loops, harnesses that
+ * forbid hipMalloc.  No counterpart in the reference (its world.hit runs on host memory it already owns).
+ * Same arguments, same answers; the device copies of rays and hits live in a fixed array inside the
+ * library's code object (RT_TRACE_NOALLOC_MAX_RAYS rays: 1.5 MB of rays + 3 MB of hits per GPU, held until
+ * the process ends), so the call makes no hipMalloc / hipFree and never grows anything.  n above the
+ * maximum is RT_ERR_UNSUPPORTED (split the batch).  Every call on one GPU, from any context, uses that
+ * GPU's one array: calls that overlap in time on one GPU race (give them to one thread, or one after the
+ * other); calls on different GPUs are independent.  The host arrays are copied with hipMemcpyAsync:
+ * pass pinned memory where the runtime's own staging of pageable memory is not acceptable either. */
+#define RT_TRACE_NOALLOC_MAX_RAYS 65536
+int rt_trace_primary_noalloc(rt_context* ctx, const float* rays_host, int32_t n, float t_min, rt_hit* hits_host);
 
 /* write_color (color.h:9-26) on device memory: n_pixels float4 sums -> n_pixels x 3 bytes. */
 int rt_quantize(rt_context* ctx, const float* rgba_device, int64_t n_pixels, int32_t spp,

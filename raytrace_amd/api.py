@@ -14,10 +14,11 @@ RT_OK = 0
 RT_ERR_INVALID, RT_ERR_NO_DEVICE, RT_ERR_HIP, RT_ERR_NO_SCENE, RT_ERR_NO_CAMERA, RT_ERR_UNSUPPORTED = \
     -1, -2, -3, -4, -5, -6
 RT_ACCEL_AUTO, RT_ACCEL_LIST, RT_ACCEL_BVH, RT_ACCEL_BVH_DEVICE = 0, 1, 2, 3
+TRACE_NOALLOC_MAX_RAYS = 65536           # RT_TRACE_NOALLOC_MAX_RAYS
 RT_FLAG_MEAN, RT_FLAG_NO_REFINE, RT_FLAG_COUNTERS, RT_FLAG_PHASE_CLOCKS, RT_FLAG_NO_LDS_SCENE = 1, 2, 4, 8, 32
 
 EXPORTS = ["rt_create", "rt_destroy", "rt_set_stream", "rt_upload_scene", "rt_set_camera",
-           "rt_shard_rows", "rt_render", "rt_render_host", "rt_trace_primary", "rt_quantize",
+           "rt_shard_rows", "rt_render", "rt_render_host", "rt_trace_primary", "rt_trace_primary_noalloc", "rt_quantize",
            "rt_get_stats", "rt_last_error", "rt_version",
            "rt_decode_jpeg", "rt_load_jpeg_file", "rt_free_image", "rt_image_last_error"]
 
@@ -105,6 +106,7 @@ def lib():
         L.rt_render.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.c_void_p]
         L.rt_render_host.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.c_void_p]
         L.rt_trace_primary.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_void_p]
+        L.rt_trace_primary_noalloc.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_void_p]
         L.rt_quantize.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]
         L.rt_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
         L.rt_last_error.argtypes = [C.c_void_p]
@@ -250,11 +252,13 @@ class Context:
         self._check(lib().rt_render_host(self._h, C.byref(params), out.ctypes.data))
         return out
 
-    def trace_primary(self, rays, t_min=0.001):
+    def trace_primary(self, rays, t_min=0.001, noalloc=False):
+        """noalloc: through rt_trace_primary_noalloc (fixed device staging, at most
+        TRACE_NOALLOC_MAX_RAYS rays, no device allocation in the call)."""
         rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
         hits = np.zeros(rays.shape[0], HIT_DTYPE)
-        self._check(lib().rt_trace_primary(self._h, rays.ctypes.data, rays.shape[0], C.c_float(t_min),
-                                           hits.ctypes.data))
+        fn = lib().rt_trace_primary_noalloc if noalloc else lib().rt_trace_primary
+        self._check(fn(self._h, rays.ctypes.data, rays.shape[0], C.c_float(t_min), hits.ctypes.data))
         return hits
 
     def quantize(self, rgba_device_ptr, n_pixels, spp, rgb8_device_ptr):

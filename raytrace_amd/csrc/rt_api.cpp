@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -38,9 +39,41 @@ struct rt_context {
     int last_k = 0;
     float4* staging = nullptr;                // device image for rt_render_host
     size_t staging_bytes = 0;
+    unsigned char* noalloc = nullptr;         // this device's address of the fixed staging array of rt_trace_primary_noalloc
 };
 
 namespace {
+
+// ---- rt_trace_primary_noalloc: device staging that is never allocated -------------------------------
+// The device copies of the rays and of the hits of rt_trace_primary_noalloc live in this array, which
+// is part of the library's code object: every GPU the library runs on holds its own copy at its own
+// address from the moment the code object is loaded until the process ends.  In host code the name
+// `scratch` is only a handle for hipGetSymbolAddress; the address a kernel or a copy may use is the
+// one that call returns, looked up once per device (rt_create) and kept in g_scratch_ptr.
+constexpr size_t kNoAllocRayBytes = (size_t)RT_TRACE_NOALLOC_MAX_RAYS * 6 * sizeof(float);
+constexpr size_t kNoAllocHitBytes = (size_t)RT_TRACE_NOALLOC_MAX_RAYS * sizeof(rt::Hit);
+static __device__ __align__(256) unsigned char scratch[kNoAllocRayBytes + kNoAllocHitBytes];
+static_assert(kNoAllocRayBytes % 256 == 0, "the hits start on a 256-byte boundary");
+
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mutex;
+unsigned char* g_scratch_ptr[kMaxDevices] = {};
+
+// Device address of `scratch` on `device`, which must be the current device.
+hipError_t resolve_scratch(int device, unsigned char** out) {
+    *out = nullptr;
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        void* p = nullptr;
+        hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        if (!p) return hipErrorInvalidSymbol;
+        g_scratch_ptr[device] = static_cast<unsigned char*>(p);
+    }
+    *out = g_scratch_ptr[device];
+    return hipSuccess;
+}
 
 int fail(rt_context* ctx, int code, const std::string& msg) {
     if (ctx) ctx->error = msg;
@@ -210,7 +243,8 @@ int rt_create(int device, rt_context** out) {
     ctx->device = device;
     DeviceGuard g(device);
     if (hipMalloc((void**)&ctx->counters, rt::kNumCounterSlots * sizeof(unsigned long long)) != hipSuccess ||
-        hipEventCreate(&ctx->ev_start) != hipSuccess || hipEventCreate(&ctx->ev_stop) != hipSuccess) {
+        hipEventCreate(&ctx->ev_start) != hipSuccess || hipEventCreate(&ctx->ev_stop) != hipSuccess ||
+        resolve_scratch(device, &ctx->noalloc) != hipSuccess) {
         rt_destroy(ctx);
         return RT_ERR_HIP;
     }
@@ -555,6 +589,30 @@ int rt_trace_primary(rt_context* ctx, const float* rays_host, int32_t n, float t
     (void)hipFree(d_rays);
     if (d_hits) (void)hipFree(d_hits);
     if (e != hipSuccess) return fail(ctx, RT_ERR_HIP, std::string("rt_trace_primary: ") + hipGetErrorString(e));
+    return RT_OK;
+}
+
+int rt_trace_primary_noalloc(rt_context* ctx, const float* rays_host, int32_t n, float t_min, rt_hit* hits_host) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (!ctx->has_scene) return fail(ctx, RT_ERR_NO_SCENE, "no scene uploaded");
+    if (n < 0 || (n > 0 && (!rays_host || !hits_host))) return fail(ctx, RT_ERR_INVALID, "bad ray arrays");
+    if (!(t_min >= 0.0f)) return fail(ctx, RT_ERR_INVALID, "t_min must be >= 0");
+    if (n > RT_TRACE_NOALLOC_MAX_RAYS)
+        return fail(ctx, RT_ERR_UNSUPPORTED, "rt_trace_primary_noalloc: " + std::to_string(n) + " rays exceed the fixed staging array of " +
+                                             std::to_string(RT_TRACE_NOALLOC_MAX_RAYS) + " (split the batch, or use rt_trace_primary)");
+    if (n == 0) return RT_OK;
+    if (!ctx->noalloc) return fail(ctx, RT_ERR_HIP, "rt_trace_primary_noalloc: the staging array has no device address");
+    DeviceGuard g(ctx->device);
+    // rays in the first part of the array, hits behind them.  Nothing has to start at zero: the
+    // copy writes rays [0, n), the kernel writes every hit of [0, n) and only those are read back,
+    // so what an earlier (longer) call left behind n is never looked at.
+    float* d_rays = reinterpret_cast<float*>(ctx->noalloc);
+    rt::Hit* d_hits = reinterpret_cast<rt::Hit*>(ctx->noalloc + kNoAllocRayBytes);
+    hipError_t e = hipMemcpyAsync(d_rays, rays_host, (size_t)n * 6 * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = rt::launch_trace(ctx->scene, d_rays, n, t_min == 0.0f ? 0.001f : t_min, 0u, d_hits, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(hits_host, d_hits, (size_t)n * sizeof(rt::Hit), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) return fail(ctx, RT_ERR_HIP, std::string("rt_trace_primary_noalloc: ") + hipGetErrorString(e));
     return RT_OK;
 }
 
