@@ -108,7 +108,12 @@ enum {
     RT_FLAG_NO_REFINE = 1u << 1,  /* skip the double-precision polish of the winning hit */
     RT_FLAG_COUNTERS = 1u << 2,   /* also count box/sphere/rect tests (slower; for the roofline) */
     RT_FLAG_PHASE_CLOCKS = 1u << 3, /* diagnostic build: wave clocks per phase into rt_stats.phase_clocks */
-    RT_FLAG_NO_LDS_SCENE = 1u << 5 /* read BVH and spheres from HBM even when they would fit in LDS */
+    RT_FLAG_NO_LDS_SCENE = 1u << 5, /* read BVH and spheres from HBM even when they would fit in LDS */
+    RT_FLAG_FIXED_SUMS = 1u << 6  /* the image is written as the kernel accumulates it: per pixel four uint64_t
+                                     (r, g, b sums of sample radiance in unsigned 32.32 fixed point, sample
+                                     count), 32 bytes.  Integer sums of sample windows (sample_begin) add up
+                                     exactly, in any order: rt_resolve_sums of the added windows is bit for bit
+                                     the frame one call renders with all the samples.  Excludes RT_FLAG_MEAN. */
 };
 
 typedef struct rt_render_params {
@@ -125,6 +130,13 @@ typedef struct rt_render_params {
     uint32_t flags;              /* RT_FLAG_* */
     int32_t lanes_per_pixel;     /* K = 1,2,4,...,64: a wavefront's tile holds 64/K pixels whose samples its
                                     64 lanes take dynamically; 0 = choose from the frame size */
+    /* Traversal tuning (the image does not depend on either).  A struct whose struct_size ends before
+     * traversal_slice leaves both at their defaults. */
+    int32_t traversal_slice;     /* BVH node steps a wavefront spends per trip of its path loop before lanes whose
+                                    rays are finished shade and start new rays: 0 = chosen from the tree depth,
+                                    -1 = never leave a walk early, n > 0 = n steps */
+    int32_t leaf_quorum;         /* time-sliced walk: leaves are tested once (lanes waiting at a leaf) x this
+                                    >= lanes still walking; 0 = default (2), -1 = wait for every lane */
 } rt_render_params;
 
 /* one closest-hit answer (hit_record of sceneobject.h:9-14 plus the object's list position) */
@@ -161,13 +173,14 @@ int rt_set_camera(rt_context* ctx, const rt_camera_desc* camera);
 /* Rows this call would render for the given sharding (for sizing the output buffer). */
 int rt_shard_rows(int32_t height, int32_t tile_rows, int32_t tile_first, int32_t tile_step);
 
-/* Render into DEVICE memory: rgba_device holds rt_shard_rows(..) * width float4.  Asynchronous
- * on the context's stream. */
+/* Render into DEVICE memory: rgba_device holds rt_shard_rows(..) * width float4 (with
+ * RT_FLAG_FIXED_SUMS: as many 4 x uint64_t).  Asynchronous on the context's stream. */
 int rt_render(rt_context* ctx, const rt_render_params* params, float* rgba_device);
 /* Same into HOST memory; returns when the image is there. */
 int rt_render_host(rt_context* ctx, const rt_render_params* params, float* rgba_host);
 
-/* Closest hit of n explicit rays (host arrays; rays = n x (ox oy oz dx dy dz)). */
+/* Closest hit of n explicit rays (host arrays; rays = n x (ox oy oz dx dy dz)).  The device copies of
+ * rays and hits live in a buffer the context keeps, and grows when n exceeds every earlier n. */
 int rt_trace_primary(rt_context* ctx, const float* rays_host, int32_t n, float t_min, rt_hit* hits_host);
 
 /* rt_trace_primary for callers that cannot allocate device memory: tight serving loops, harnesses that
@@ -185,6 +198,11 @@ int rt_trace_primary_noalloc(rt_context* ctx, const float* rays_host, int32_t n,
 /* write_color (color.h:9-26) on device memory: n_pixels float4 sums -> n_pixels x 3 bytes. */
 int rt_quantize(rt_context* ctx, const float* rgba_device, int64_t n_pixels, int32_t spp,
                 uint8_t* rgb8_device);
+
+/* RT_FLAG_FIXED_SUMS images -> float4 images: n_pixels x (r, g, b, samples) uint64_t in device memory become
+ * n_pixels float4 (rgb = sum, or mean with mean != 0; a = samples), exactly as rt_render converts its own
+ * sums.  Asynchronous on the context's stream. */
+int rt_resolve_sums(rt_context* ctx, const uint64_t* sums_device, int64_t n_pixels, int32_t mean, float* rgba_device);
 
 /* Waits for the context's stream, then reports the last render. */
 int rt_get_stats(rt_context* ctx, rt_stats* out);

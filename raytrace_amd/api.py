@@ -15,11 +15,11 @@ RT_ERR_INVALID, RT_ERR_NO_DEVICE, RT_ERR_HIP, RT_ERR_NO_SCENE, RT_ERR_NO_CAMERA,
     -1, -2, -3, -4, -5, -6
 RT_ACCEL_AUTO, RT_ACCEL_LIST, RT_ACCEL_BVH, RT_ACCEL_BVH_DEVICE = 0, 1, 2, 3
 TRACE_NOALLOC_MAX_RAYS = 65536           # RT_TRACE_NOALLOC_MAX_RAYS
-RT_FLAG_MEAN, RT_FLAG_NO_REFINE, RT_FLAG_COUNTERS, RT_FLAG_PHASE_CLOCKS, RT_FLAG_NO_LDS_SCENE = 1, 2, 4, 8, 32
+RT_FLAG_MEAN, RT_FLAG_NO_REFINE, RT_FLAG_COUNTERS, RT_FLAG_PHASE_CLOCKS, RT_FLAG_NO_LDS_SCENE, RT_FLAG_FIXED_SUMS = 1, 2, 4, 8, 32, 64
 
 EXPORTS = ["rt_create", "rt_destroy", "rt_set_stream", "rt_upload_scene", "rt_set_camera",
            "rt_shard_rows", "rt_render", "rt_render_host", "rt_trace_primary", "rt_trace_primary_noalloc", "rt_quantize",
-           "rt_get_stats", "rt_last_error", "rt_version",
+           "rt_resolve_sums", "rt_get_stats", "rt_last_error", "rt_version",
            "rt_decode_jpeg", "rt_load_jpeg_file", "rt_free_image", "rt_image_last_error"]
 
 
@@ -53,7 +53,7 @@ class RenderParams(C.Structure):
                 ("spp", C.c_int32), ("sample_begin", C.c_int32), ("max_depth", C.c_int32),
                 ("seed", C.c_uint64), ("tile_rows", C.c_int32), ("tile_first", C.c_int32),
                 ("tile_step", C.c_int32), ("t_min", C.c_float), ("flags", C.c_uint32),
-                ("lanes_per_pixel", C.c_int32)]
+                ("lanes_per_pixel", C.c_int32), ("traversal_slice", C.c_int32), ("leaf_quorum", C.c_int32)]
 
 
 class Hit(C.Structure):
@@ -108,6 +108,7 @@ def lib():
         L.rt_trace_primary.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_void_p]
         L.rt_trace_primary_noalloc.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_void_p]
         L.rt_quantize.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]
+        L.rt_resolve_sums.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]
         L.rt_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
         L.rt_last_error.argtypes = [C.c_void_p]
         L.rt_last_error.restype = C.c_char_p
@@ -226,13 +227,14 @@ class Context:
 
     @staticmethod
     def params(width, height, spp, max_depth=50, seed=1, sample_begin=0, tiles=(0, 0, 0), t_min=0.0,
-               flags=0, lanes_per_pixel=0):
+               flags=0, lanes_per_pixel=0, traversal_slice=0, leaf_quorum=0):
         p = RenderParams()
         p.struct_size = C.sizeof(RenderParams)
         p.width, p.height, p.spp, p.sample_begin, p.max_depth = width, height, spp, sample_begin, max_depth
         p.seed = seed
         p.tile_rows, p.tile_first, p.tile_step = tiles
         p.t_min, p.flags, p.lanes_per_pixel = t_min, flags, lanes_per_pixel
+        p.traversal_slice, p.leaf_quorum = traversal_slice, leaf_quorum
         return p
 
     @staticmethod
@@ -248,7 +250,8 @@ class Context:
 
     def render_host(self, params):
         rows = self.shard_rows(params.height, (params.tile_rows, params.tile_first, params.tile_step))
-        out = np.empty((rows, params.width, 4), np.float32)
+        # RT_FLAG_FIXED_SUMS: (r, g, b sums in 32.32 fixed point, samples) as uint64 per pixel
+        out = np.empty((rows, params.width, 4), np.uint64 if params.flags & RT_FLAG_FIXED_SUMS else np.float32)
         self._check(lib().rt_render_host(self._h, C.byref(params), out.ctypes.data))
         return out
 
@@ -264,6 +267,11 @@ class Context:
     def quantize(self, rgba_device_ptr, n_pixels, spp, rgb8_device_ptr):
         self._check(lib().rt_quantize(self._h, C.c_void_p(rgba_device_ptr), n_pixels, spp,
                                       C.c_void_p(rgb8_device_ptr)))
+
+    def resolve_sums(self, sums_device_ptr, n_pixels, rgba_device_ptr, mean=False):
+        """RT_FLAG_FIXED_SUMS image (device) -> float4 image (device), as rt_render converts its own sums."""
+        self._check(lib().rt_resolve_sums(self._h, C.c_void_p(sums_device_ptr), n_pixels, int(bool(mean)),
+                                          C.c_void_p(rgba_device_ptr)))
 
     def stats(self):
         s = Stats()

@@ -39,6 +39,8 @@ struct rt_context {
     int last_k = 0;
     float4* staging = nullptr;                // device image for rt_render_host
     size_t staging_bytes = 0;
+    unsigned char* trace_buf = nullptr;       // device copies of rays and hits for rt_trace_primary (grown on demand)
+    size_t trace_rays = 0;                    // rays it holds
     unsigned char* noalloc = nullptr;         // this device's address of the fixed staging array of rt_trace_primary_noalloc
 };
 
@@ -170,7 +172,9 @@ int choose_lanes_per_pixel(long long pixels, int spp) {
 
 int validate_render(rt_context* ctx, const rt_render_params* p, rt::DRender* rp) {
     if (!ctx) return RT_ERR_INVALID;
-    if (!p || p->struct_size != sizeof(rt_render_params))
+    // two layouts are accepted: the whole struct, or the one that ends before the traversal tuning fields
+    const bool has_tuning = p && p->struct_size == sizeof(rt_render_params);
+    if (!p || (!has_tuning && p->struct_size != offsetof(rt_render_params, traversal_slice)))
         return fail(ctx, RT_ERR_INVALID, "rt_render_params: null or struct_size mismatch");
     if (!ctx->has_scene) return fail(ctx, RT_ERR_NO_SCENE, "no scene uploaded");
     if (!ctx->has_camera) return fail(ctx, RT_ERR_NO_CAMERA, "no camera set");
@@ -203,18 +207,16 @@ int validate_render(rt_context* ctx, const rt_render_params* p, rt::DRender* rp)
     rp->lanes_per_pixel = k;
     rp->inv_wm1 = (float)(1.0 / (double)(p->width - 1));
     rp->inv_hm1 = (float)(1.0 / (double)(p->height - 1));
-    {
-        // RT_TUNE_SLICE (an integer) overrides the traversal time slice for tuning runs
-        // (tools/tune_probe.py); unset in normal use
-        const char* v = std::getenv("RT_TUNE_SLICE");
-        rp->slice = v && *v ? std::atoi(v) : 0x7fffffff;      // 0x7fffffff: chosen at launch from the tree depth
-        const char* q = std::getenv("RT_TUNE_QUORUM");
-        rp->leaf_quorum = q && *q ? std::atoi(q) : -1;       // -1: default ratio
-    }
+    const int slice = has_tuning ? p->traversal_slice : 0, quorum = has_tuning ? p->leaf_quorum : 0;
+    if (slice < -1 || quorum < -1) return fail(ctx, RT_ERR_INVALID, "traversal_slice and leaf_quorum must be >= -1");
+    rp->slice = slice == 0 ? 0x7fffffff : (slice < 0 ? 0 : slice);      // device side: 0x7fffffff = chosen at launch from the tree depth, 0 = unsliced
+    rp->leaf_quorum = quorum == 0 ? -1 : (quorum < 0 ? 0 : quorum);     // device side: -1 = default ratio, 0 = wait for all
+    if ((p->flags & RT_FLAG_FIXED_SUMS) && (p->flags & RT_FLAG_MEAN))
+        return fail(ctx, RT_ERR_INVALID, "RT_FLAG_FIXED_SUMS excludes RT_FLAG_MEAN (take the mean in rt_resolve_sums)");
     return RT_OK;
 }
 
-int do_render(rt_context* ctx, const rt::DRender& rp, float4* out_dev) {
+int do_render(rt_context* ctx, const rt::DRender& rp, float4* out_dev) {   // with RT_FLAG_FIXED_SUMS out_dev holds 32 bytes per pixel
     RT_HIP(ctx, hipMemsetAsync(ctx->counters, 0, rt::kNumCounterSlots * sizeof(unsigned long long), ctx->stream));
     RT_HIP(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
     RT_HIP(ctx, rt::launch_render(ctx->scene, ctx->camera, rp, out_dev, ctx->counters, ctx->stream));
@@ -259,6 +261,7 @@ void rt_destroy(rt_context* ctx) {
     free_scene(ctx);
     if (ctx->counters) (void)hipFree(ctx->counters);
     if (ctx->staging) (void)hipFree(ctx->staging);
+    if (ctx->trace_buf) (void)hipFree(ctx->trace_buf);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
     delete ctx;
@@ -298,6 +301,8 @@ int rt_upload_scene(rt_context* ctx, const rt_scene_desc* d) {
         return fail(ctx, RT_ERR_INVALID, "texture arrays missing");
     if (d->accel < RT_ACCEL_AUTO || d->accel > RT_ACCEL_BVH_DEVICE) return fail(ctx, RT_ERR_INVALID, "unknown accel");
     if (d->background != RT_BG_SKY && d->background != RT_BG_SOLID) return fail(ctx, RT_ERR_INVALID, "unknown background");
+    // leaf codes hold first << kLeafBits | count - 1 in 31 bits, Origin codes an index in 28
+    static_assert((1LL << 28) <= (0x7fffffffLL >> rt::kLeafBits) + 1, "a leaf code holds any sphere index");
     if (d->n_prims > (1 << 28)) return fail(ctx, RT_ERR_UNSUPPORTED, "more than 2^28 primitives");
     const double wide_radius = d->wide_radius > 0 ? d->wide_radius : 64.0;
 
@@ -433,76 +438,85 @@ int rt_upload_scene(rt_context* ctx, const rt_scene_desc* d) {
     // the GPU builder needs an inner root; a handful of spheres goes through the host builder
     // RT_ACCEL_AUTO: from 65536 spheres on the host build (0.5 s per million) costs more than the
     // few percent of traversal time its tree saves on a frame
-    const bool device_build = (d->accel == RT_ACCEL_BVH_DEVICE && ns > 4) || (d->accel == RT_ACCEL_AUTO && ns >= 65536);
+    bool device_build = (d->accel == RT_ACCEL_BVH_DEVICE && ns > 4) || (d->accel == RT_ACCEL_AUTO && ns >= 65536);
     const auto t_build = std::chrono::steady_clock::now();
-    rt::BvhResult bvh;
-    std::vector<int32_t> order((size_t)ns);
-    for (int64_t i = 0; i < ns; i++) order[i] = (int32_t)i;
-    if (use_bvh && !device_build) {
-        bvh = rt::build_bvh(sc_c.data(), sc_r.data(), ns, rt::kMaxStack - 4);
-        if (bvh.depth > rt::kMaxStack - 2) return fail(ctx, RT_ERR_UNSUPPORTED, "BVH deeper than the traversal stack");
-        order = bvh.order;
-    }
-    // sphere arrays in leaf order (input order when the GPU builder will permute them)
-    // a multiple of four (the linear scan's group size) plus four (a leaf is read as four records)
-    const int64_t ns_pad = (ns + 3) / 4 * 4 + 4;
-    std::vector<float4> sph((size_t)ns_pad, make_float4(1e30f, 1e30f, 1e30f, 0.0f));
-    std::vector<double4> sph64((size_t)ns_pad, make_double4(1e30, 1e30, 1e30, 1.0));
-    std::vector<int2> info((size_t)ns_pad, make_int2(-1, 0));
-    std::vector<int> sph_xf(any_sphere_xf ? (size_t)ns_pad : 0, 0);
-    for (int64_t k = 0; k < ns; k++) {
-        int32_t i = order[k];
-        if (any_sphere_xf) sph_xf[k] = sc_xf[i];
-        sph[k] = make_float4((float)sc_c[3 * i], (float)sc_c[3 * i + 1], (float)sc_c[3 * i + 2], (float)std::fabs(sc_r[i]));
-        sph64[k] = make_double4(sc_c[3 * i], sc_c[3 * i + 1], sc_c[3 * i + 2], sc_r[i]);
-        info[k] = make_int2(sc_obj[i], sc_mat[i]);
-    }
-
     DeviceGuard g(ctx->device);
-    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    free_scene(ctx);
     rt::DScene s{};
-    int rc;
-    std::vector<float4> nodes4(bvh.nodes.size() / 4);
-    if (!nodes4.empty()) std::memcpy(nodes4.data(), bvh.nodes.data(), bvh.nodes.size() * sizeof(float));
-    std::vector<uint8_t> texels;
-    if (d->texel_bytes && d->texels) texels.assign(d->texels, d->texels + d->texel_bytes);
-    if ((rc = upload(ctx, sph, &s.sph)) || (rc = upload(ctx, sph64, &s.sph64)) || (rc = upload(ctx, info, &s.sph_info)) ||
-        (rc = upload(ctx, nodes4, &s.nodes)) || (rc = upload(ctx, wide, &s.wide)) || (rc = upload(ctx, rects, &s.rects)) || (rc = upload(ctx, rect_k, &s.rect_k)) ||
-        (rc = upload(ctx, xforms, &s.xforms)) || (rc = upload(ctx, sph_xf, &s.sph_xform)) ||
-        (rc = upload(ctx, mats, &s.mats)) || (rc = upload(ctx, texs, &s.texs)) || (rc = upload(ctx, texels, &s.texels))) {
-        std::string keep = ctx->error;
+    int n_nodes = 0, root = rt::kNoBvh, depth = 0;
+    for (;;) {
+        rt::BvhResult bvh;
+        std::vector<int32_t> order((size_t)ns);
+        for (int64_t i = 0; i < ns; i++) order[i] = (int32_t)i;
+        if (use_bvh && !device_build) {
+            bvh = rt::build_bvh(sc_c.data(), sc_r.data(), ns, rt::kMaxStack - 4);
+            if (bvh.depth > rt::kMaxStack - 2) return fail(ctx, RT_ERR_UNSUPPORTED, "BVH deeper than the traversal stack");
+            order = bvh.order;
+        }
+        // sphere arrays in leaf order (input order when the GPU builder will permute them)
+        // a multiple of four (the linear scan's group size) plus four (a leaf is read as four records)
+        const int64_t ns_pad = (ns + 3) / 4 * 4 + 4;
+        std::vector<float4> sph((size_t)ns_pad, make_float4(1e30f, 1e30f, 1e30f, 0.0f));
+        std::vector<double4> sph64((size_t)ns_pad, make_double4(1e30, 1e30, 1e30, 1.0));
+        std::vector<int2> info((size_t)ns_pad, make_int2(-1, 0));
+        std::vector<int> sph_xf(any_sphere_xf ? (size_t)ns_pad : 0, 0);
+        for (int64_t k = 0; k < ns; k++) {
+            int32_t i = order[k];
+            if (any_sphere_xf) sph_xf[k] = sc_xf[i];
+            sph[k] = make_float4((float)sc_c[3 * i], (float)sc_c[3 * i + 1], (float)sc_c[3 * i + 2], (float)std::fabs(sc_r[i]));
+            sph64[k] = make_double4(sc_c[3 * i], sc_c[3 * i + 1], sc_c[3 * i + 2], sc_r[i]);
+            info[k] = make_int2(sc_obj[i], sc_mat[i]);
+        }
+
+        RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
         free_scene(ctx);
-        ctx->error = keep;
-        return rc;
-    }
-    int n_nodes = (int)(bvh.nodes.size() / 16), root = use_bvh ? bvh.root : rt::kNoBvh, depth = bvh.depth;
-    if (device_build) {
-        // build over the uploaded (input order) spheres, then permute the arrays into leaf
-        // order; the second set of arrays starts as a copy so that it carries the padding
-        rt::LbvhResult lb;
-        hipError_t e = rt::build_lbvh(s.sph64, (int)ns, ctx->stream, &lb);
-        const float4* sph2 = nullptr; const double4* sph642 = nullptr; const int2* info2 = nullptr; const int* xf2 = nullptr;
-        if (e == hipSuccess) {
-            ctx->scene_allocs.push_back(lb.nodes);
-            if (lb.depth > rt::kMaxStack - 2) e = hipErrorInvalidValue;
-        }
-        if (e == hipSuccess && ((rc = upload(ctx, sph, &sph2)) || (rc = upload(ctx, sph64, &sph642)) ||
-                                (rc = upload(ctx, info, &info2)) || (rc = upload(ctx, sph_xf, &xf2)))) e = hipErrorOutOfMemory;
-        if (e == hipSuccess)
-            e = rt::gather_spheres(lb.order, (int)ns, s.sph, s.sph64, s.sph_info, s.sph_xform, const_cast<float4*>(sph2),
-                                   const_cast<double4*>(sph642), const_cast<int2*>(info2), const_cast<int*>(xf2), ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        if (lb.order) (void)hipFree(lb.order);
-        if (e != hipSuccess) {
+        s = rt::DScene{};
+        int rc;
+        std::vector<float4> nodes4(bvh.nodes.size() / 4);
+        if (!nodes4.empty()) std::memcpy(nodes4.data(), bvh.nodes.data(), bvh.nodes.size() * sizeof(float));
+        std::vector<uint8_t> texels;
+        if (d->texel_bytes && d->texels) texels.assign(d->texels, d->texels + d->texel_bytes);
+        if ((rc = upload(ctx, sph, &s.sph)) || (rc = upload(ctx, sph64, &s.sph64)) || (rc = upload(ctx, info, &s.sph_info)) ||
+            (rc = upload(ctx, nodes4, &s.nodes)) || (rc = upload(ctx, wide, &s.wide)) || (rc = upload(ctx, rects, &s.rects)) || (rc = upload(ctx, rect_k, &s.rect_k)) ||
+            (rc = upload(ctx, xforms, &s.xforms)) || (rc = upload(ctx, sph_xf, &s.sph_xform)) ||
+            (rc = upload(ctx, mats, &s.mats)) || (rc = upload(ctx, texs, &s.texs)) || (rc = upload(ctx, texels, &s.texels))) {
+            std::string keep = ctx->error;
             free_scene(ctx);
-            return fail(ctx, lb.depth > rt::kMaxStack - 2 ? RT_ERR_UNSUPPORTED : RT_ERR_HIP,
-                        lb.depth > rt::kMaxStack - 2 ? std::string("BVH deeper than the traversal stack")
-                                                     : std::string("GPU BVH build: ") + hipGetErrorString(e));
+            ctx->error = keep;
+            return rc;
         }
-        s.sph = sph2; s.sph64 = sph642; s.sph_info = info2; s.sph_xform = xf2;   // the input-order copies stay in scene_allocs until the next upload
-        s.nodes = lb.nodes;
-        n_nodes = lb.n_nodes; root = lb.root; depth = lb.depth;
+        n_nodes = (int)(bvh.nodes.size() / 16); root = use_bvh ? bvh.root : rt::kNoBvh; depth = bvh.depth;
+        if (device_build) {
+            // build over the uploaded (input order) spheres, then permute the arrays into leaf
+            // order; the second set of arrays starts as a copy so that it carries the padding
+            rt::LbvhResult lb;
+            hipError_t e = rt::build_lbvh(s.sph64, (int)ns, ctx->stream, &lb);
+            const float4* sph2 = nullptr; const double4* sph642 = nullptr; const int2* info2 = nullptr; const int* xf2 = nullptr;
+            if (e == hipSuccess) {
+                ctx->scene_allocs.push_back(lb.nodes);
+                if (lb.depth > rt::kMaxStack - 2) e = hipErrorInvalidValue;
+            }
+            if (e == hipSuccess && ((rc = upload(ctx, sph, &sph2)) || (rc = upload(ctx, sph64, &sph642)) ||
+                                    (rc = upload(ctx, info, &info2)) || (rc = upload(ctx, sph_xf, &xf2)))) e = hipErrorOutOfMemory;
+            if (e == hipSuccess)
+                e = rt::gather_spheres(lb.order, (int)ns, s.sph, s.sph64, s.sph_info, s.sph_xform, const_cast<float4*>(sph2),
+                                       const_cast<double4*>(sph642), const_cast<int2*>(info2), const_cast<int*>(xf2), ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            if (lb.order) (void)hipFree(lb.order);
+            if (e != hipSuccess) {
+                free_scene(ctx);
+                // the caller did not ask for this builder: a tree its Morton order makes too deep
+                // (strongly clustered or multi-scale scenes), or a failed build, goes to the host
+                // builder, whose depth is bounded
+                if (d->accel == RT_ACCEL_AUTO) { device_build = false; continue; }
+                return fail(ctx, lb.depth > rt::kMaxStack - 2 ? RT_ERR_UNSUPPORTED : RT_ERR_HIP,
+                            lb.depth > rt::kMaxStack - 2 ? std::string("BVH deeper than the traversal stack")
+                                                         : std::string("GPU BVH build: ") + hipGetErrorString(e));
+            }
+            s.sph = sph2; s.sph64 = sph642; s.sph_info = info2; s.sph_xform = xf2;   // the input-order copies stay in scene_allocs until the next upload
+            s.nodes = lb.nodes;
+            n_nodes = lb.n_nodes; root = lb.root; depth = lb.depth;
+        }
+        break;
     }
     ctx->build_ms = use_bvh ? std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_build).count() : 0.0f;
     s.n_sph = (int)ns;
@@ -557,7 +571,7 @@ int rt_render_host(rt_context* ctx, const rt_render_params* params, float* rgba_
     if (rc) return rc;
     if (!rgba_host) return fail(ctx, RT_ERR_INVALID, "null output");
     DeviceGuard g(ctx->device);
-    size_t bytes = (size_t)rp.rows * rp.width * sizeof(float4);
+    size_t bytes = (size_t)rp.rows * rp.width * ((rp.flags & RT_FLAG_FIXED_SUMS) ? 4 * sizeof(uint64_t) : sizeof(float4));
     if (bytes > ctx->staging_bytes) {
         if (ctx->staging) (void)hipFree(ctx->staging);
         ctx->staging = nullptr; ctx->staging_bytes = 0;
@@ -578,16 +592,20 @@ int rt_trace_primary(rt_context* ctx, const float* rays_host, int32_t n, float t
     if (n == 0) return RT_OK;
     static_assert(sizeof(rt_hit) == sizeof(rt::Hit), "rt_hit layout");
     DeviceGuard g(ctx->device);
-    float* d_rays = nullptr;
-    rt::Hit* d_hits = nullptr;
-    RT_HIP(ctx, hipMalloc((void**)&d_rays, (size_t)n * 6 * sizeof(float)));
-    hipError_t e = hipMalloc((void**)&d_hits, (size_t)n * sizeof(rt::Hit));
-    if (e == hipSuccess) e = hipMemcpyAsync(d_rays, rays_host, (size_t)n * 6 * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+    // rays in the first part of the context's buffer, hits behind them (on a 256-byte boundary)
+    if ((size_t)n > ctx->trace_rays) {
+        if (ctx->trace_buf) (void)hipFree(ctx->trace_buf);
+        ctx->trace_buf = nullptr; ctx->trace_rays = 0;
+        const size_t cap = ((size_t)n + 1023) / 1024 * 1024;
+        RT_HIP(ctx, hipMalloc((void**)&ctx->trace_buf, cap * (6 * sizeof(float) + sizeof(rt::Hit))));
+        ctx->trace_rays = cap;
+    }
+    float* d_rays = reinterpret_cast<float*>(ctx->trace_buf);
+    rt::Hit* d_hits = reinterpret_cast<rt::Hit*>(ctx->trace_buf + ctx->trace_rays * 6 * sizeof(float));
+    hipError_t e = hipMemcpyAsync(d_rays, rays_host, (size_t)n * 6 * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = rt::launch_trace(ctx->scene, d_rays, n, t_min == 0.0f ? 0.001f : t_min, 0u, d_hits, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(hits_host, d_hits, (size_t)n * sizeof(rt::Hit), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    (void)hipFree(d_rays);
-    if (d_hits) (void)hipFree(d_hits);
     if (e != hipSuccess) return fail(ctx, RT_ERR_HIP, std::string("rt_trace_primary: ") + hipGetErrorString(e));
     return RT_OK;
 }
@@ -622,6 +640,16 @@ int rt_quantize(rt_context* ctx, const float* rgba_device, int64_t n_pixels, int
         return fail(ctx, RT_ERR_INVALID, "rt_quantize: bad arguments");
     DeviceGuard g(ctx->device);
     RT_HIP(ctx, rt::launch_quantize(reinterpret_cast<const float4*>(rgba_device), n_pixels, spp, rgb8_device, ctx->stream));
+    return RT_OK;
+}
+
+int rt_resolve_sums(rt_context* ctx, const uint64_t* sums_device, int64_t n_pixels, int32_t mean, float* rgba_device) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (n_pixels < 0 || (n_pixels > 0 && (!sums_device || !rgba_device)))
+        return fail(ctx, RT_ERR_INVALID, "rt_resolve_sums: bad arguments");
+    DeviceGuard g(ctx->device);
+    RT_HIP(ctx, rt::launch_resolve(reinterpret_cast<const unsigned long long*>(sums_device), n_pixels, mean != 0,
+                                   reinterpret_cast<float4*>(rgba_device), ctx->stream));
     return RT_OK;
 }
 

@@ -53,8 +53,8 @@ struct DTexture {         // tagged union: cuda/texture.h:17-78
 };
 
 // BVH2 node, 64 B = four float4 loads.  Both children's boxes live in the parent so one
-// fetch decides both.  child >= 0: inner node index; child < 0: leaf, ~child = first << 2 |
-// (count - 1) into the leaf-ordered sphere arrays.
+// fetch decides both.  child >= 0: inner node index; child < 0: leaf, ~child = first << kLeafBits |
+// (count - 1) into the leaf-ordered sphere arrays (kLeafBits = 3 in rt_bvh.h; leaves hold at most four).
 //   q0 = (lmin.x lmin.y lmin.z lmax.x)  q1 = (lmax.y lmax.z rmin.x rmin.y)
 //   q2 = (rmin.z rmax.x rmax.y rmax.z)  q3 = (left, right, -, -) as int bits
 struct DScene {
@@ -132,6 +132,8 @@ hipError_t launch_render(const DScene& sc, const DCamera& cam, const DRender& rp
                          unsigned long long* counters, hipStream_t stream);
 hipError_t launch_trace(const DScene& sc, const float* rays, int n, float t_min, uint32_t flags,
                         Hit* out, hipStream_t stream);
+hipError_t launch_resolve(const unsigned long long* sums, long long n_pixels, bool mean, float4* rgba,
+                          hipStream_t stream);
 hipError_t launch_quantize(const float4* rgba, long long n_pixels, int spp, uint8_t* rgb8,
                            hipStream_t stream);
 

@@ -1,12 +1,14 @@
 // gfx950 kernels of the per-pixel render path: camera ray -> closest hit -> scatter ->
 // accumulate (main.cc:10-35,111-126), written for 64-wide wavefronts.
 //
-// Work decomposition: one lane owns (pixel, contiguous slice of that pixel's samples) and runs
-// a flattened path state machine: every trip of the lane loop traces ONE ray for every live
-// lane, whichever sample or bounce that lane is at, so a lane whose path ended starts its next
-// sample in the very next trip instead of idling until the wave's longest path ends.  K lanes
-// (lanes_per_pixel) share a pixel; their partial sums are combined in lane order by shuffles,
-// so an image is a pure function of (scene, camera, params) whatever the GPU count.
+// Work decomposition: persistent waves draw tiles of 64/K pixels (K = lanes_per_pixel) from a device
+// counter.  A tile's (pixel, sample) units are handed out dynamically: whenever lanes of the wave are
+// free they take the next units (ballot + mbcnt rank), and every trip of the path loop traces ONE ray
+// on every live lane, whichever sample or bounce that lane is at, so a lane whose path ended starts
+// another sample in the very next trip instead of idling until the wave's longest path ends.  A
+// pixel's radiance is summed in LDS as 32.32 fixed point with integer atomics: the sum does not
+// depend on which lane rendered which sample or in what order, so an image is a pure function of
+// (scene, camera, params) whatever K or the GPU count.
 //
 // Numerics: single precision everywhere except (a) spheres flagged "wide" (radius above
 // rt_scene_desc.wide_radius: the r = 1000 ground of main.cc:42), whose quadratic cancels
@@ -435,7 +437,8 @@ __device__ __forceinline__ void hit_own_sphere(const G& geo, V3 o, const RayN& r
 // wave leaves after about that many node steps; lanes whose traversal is not finished
 // (cur != kTravDone) come back later with the same state, so one long ray does not hold the
 // other 63 lanes of the wave.
-constexpr int kTravDone = (int)0x80000000;     // not a leaf code: ~kTravDone >> 2 exceeds any sphere count
+constexpr int kTravDone = (int)0x80000000;     // not a leaf code: ~kTravDone >> kLeafBits = 2^28 - 1 with count 8, and a leaf
+                                               // holds at most four spheres of at most 2^28 (rt_upload_scene's limit)
 
 template <bool COUNT, bool SLICED, class G>
 __device__ __forceinline__ void hit_bvh(const G& geo, V3 o, const RayN& rn, Origin from, int* stack, int budget, int quorum,
@@ -1008,9 +1011,16 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? RT_WG_PER_CU_SCAN : RT_WG_PER_C
             if (tile_pix[slot].x >= 0) {
                 const unsigned long long* acc = accum + slot * 3;
                 float a = (float)rp.spp;
-                V3 total_rgb = mk(from_fixed(acc[0]), from_fixed(acc[1]), from_fixed(acc[2]));
-                if (rp.flags & 1u) total_rgb = (1.0f / a) * total_rgb;
-                out[(size_t)(tile_row[buf] + lane / TW) * rp.width + tile_pix[slot].x] = make_float4(total_rgb.x, total_rgb.y, total_rgb.z, a);
+                const size_t at = (size_t)(tile_row[buf] + lane / TW) * rp.width + tile_pix[slot].x;
+                if (rp.flags & 64u) {                  // the sums as they are: two 16-byte stores per pixel
+                    ulonglong2* o2 = reinterpret_cast<ulonglong2*>(out) + 2 * at;
+                    o2[0] = make_ulonglong2(acc[0], acc[1]);
+                    o2[1] = make_ulonglong2(acc[2], (unsigned long long)rp.spp);
+                } else {
+                    V3 total_rgb = mk(from_fixed(acc[0]), from_fixed(acc[1]), from_fixed(acc[2]));
+                    if (rp.flags & 1u) total_rgb = (1.0f / a) * total_rgb;
+                    out[at] = make_float4(total_rgb.x, total_rgb.y, total_rgb.z, a);
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -1184,7 +1194,27 @@ __global__ __launch_bounds__(kBlock) void quantize_kernel(const float4* __restri
     }
 }
 
+// Fixed-point sums (RT_FLAG_FIXED_SUMS layout: r, g, b, samples per pixel) -> float4, the conversion
+// render_kernel applies to its own sums.
+__global__ __launch_bounds__(kBlock) void resolve_kernel(const ulonglong2* __restrict__ sums, long long n, int mean,
+                                                         float4* __restrict__ rgba) {
+    long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const ulonglong2 a = sums[2 * i], b = sums[2 * i + 1];
+    const float spp = (float)b.y;
+    V3 total_rgb = mk(from_fixed(a.x), from_fixed(a.y), from_fixed(b.x));
+    if (mean) total_rgb = (1.0f / spp) * total_rgb;
+    rgba[i] = make_float4(total_rgb.x, total_rgb.y, total_rgb.z, spp);
+}
+
 }  // namespace
+
+hipError_t launch_resolve(const unsigned long long* sums, long long n_pixels, bool mean, float4* rgba, hipStream_t stream) {
+    if (n_pixels <= 0) return hipSuccess;
+    hipLaunchKernelGGL(resolve_kernel, dim3((unsigned)((n_pixels + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream,
+                       reinterpret_cast<const ulonglong2*>(sums), n_pixels, mean ? 1 : 0, rgba);
+    return hipGetLastError();
+}
 
 hipError_t launch_render(const DScene& sc, const DCamera& cam, const DRender& rp, float4* out,
                          unsigned long long* counters, hipStream_t stream) {
@@ -1211,7 +1241,8 @@ hipError_t launch_render(const DScene& sc, const DCamera& cam, const DRender& rp
     // latency a loop of one or two trips cannot hide; a long list is faster through scalar loads
     // (487 spheres: by 6 %), which run ahead of the arithmetic and cost no vector registers
     const bool in_lds = (rp.flags & 32u) == 0u && sc.n_sph > 0 &&
-                        (sc.use_bvh ? lds + geo_bytes <= 40 * 1024 && sc.ids_fit_16 : sc.n_sph_padded <= 32);
+                        sc.ids_fit_16 &&                  // the LDS copy packs list position and material into one word
+                        (sc.use_bvh ? lds + geo_bytes <= 40 * 1024 : sc.n_sph_padded <= 32);
     if (in_lds) lds += geo_bytes;
     const bool count = (rp.flags & 4u) != 0u;
     const bool prof = (rp.flags & 8u) != 0u;

@@ -117,14 +117,8 @@ def test_random_scene(seed, oracle):
         if accel != api.RT_ACCEL_LIST:
             # the same tree read from HBM instead of LDS, and walked in time slices (what scenes too
             # large for LDS and trees deeper than 12 levels get): the same frame, the same ray count
-            import os
-            for flags, slice_steps in ((api.RT_FLAG_NO_LDS_SCENE, None), (0, "3"), (api.RT_FLAG_NO_LDS_SCENE, "5")):
-                if slice_steps is not None:
-                    os.environ["RT_TUNE_SLICE"] = slice_steps
-                try:
-                    other = ctx.render_host(api.Context.params(W, H, spp, 50, 77 + seed, flags=flags))
-                finally:
-                    os.environ.pop("RT_TUNE_SLICE", None)
+            for flags, slice_steps in ((api.RT_FLAG_NO_LDS_SCENE, 0), (0, 3), (api.RT_FLAG_NO_LDS_SCENE, 5)):
+                other = ctx.render_host(api.Context.params(W, H, spp, 50, 77 + seed, flags=flags, traversal_slice=slice_steps))
                 assert np.array_equal(other, img), (accel, flags, slice_steps)
                 assert ctx.stats()["rays"] == st["rays"]
         if accel == api.RT_ACCEL_BVH:
