@@ -14,6 +14,9 @@
 //   rgb_color / checker_texture / image_texture   cuda/texture.h:22,39-41,61
 //   load_texture(filename)                        cuda/main.cu:385-436
 //   camera(lookfrom, lookat, vup, vfov, aspect, aperture, focus_dist)   camera.h:19-20
+//   camera(look_from, look_at, angles, vup, vfov, aspect, aperture, focus_dist), translate_camera,
+//   rotate_camera_{x,y,z}, compute_camera_scene   cuda/camera.h:29-117
+//   rotate_scene / update_scene(camera, frame)    cuda/main.cu:206-279
 //
 // Objects only record what they were built from; `flat_scene` turns a sceneobject_list into the
 // arrays rt_upload_scene takes, and `renderer` owns an rt_context.  Nothing here computes pixels.
@@ -154,13 +157,88 @@ inline shared_ptr<sceneobject_list> box(point3 p0, point3 p1, shared_ptr<materia
     return l;
 }
 
+// camera.h:19-38, and the CUDA tree's camera (cuda/camera.h:9-126): the constructor with `angles`,
+// the mutators and compute_camera_scene.  The mutators work in single precision like the
+// original (its vec3 holds floats): look_from and angles always hold float values.  The view
+// basis itself is derived by rt_set_camera from what desc() returns.
 struct camera {
-    rt_camera_desc d;
-    camera(point3 lookfrom, point3 lookat, vec3 vup, double vfov, double aspect_ratio, double aperture, double focus_dist) {
-        for (int a = 0; a < 3; a++) { d.lookfrom[a] = lookfrom[a]; d.lookat[a] = lookat[a]; d.vup[a] = vup[a]; }
+    point3 look_from, look_at;
+    vec3 angles, vup;
+    double vfov, aspect_ratio, aperture, focus_dist;
+
+    camera(point3 lookfrom, point3 lookat, vec3 vup_, double vfov_, double aspect_ratio_, double aperture_, double focus_dist_)
+        : look_from(lookfrom), look_at(lookat), angles(0, 0, 0), vup(vup_), vfov(vfov_), aspect_ratio(aspect_ratio_),
+          aperture(aperture_), focus_dist(focus_dist_) {}
+    // cuda/camera.h:29-36
+    camera(point3 look_from_, point3 look_at_, vec3 angles_, vec3 vup_, float vfov_, float aspect_ratio_, float aperture_, float focus_dist_)
+        : look_from(look_from_), look_at(look_at_), angles(angles_), vup(vup_), vfov(vfov_), aspect_ratio(aspect_ratio_),
+          aperture(aperture_), focus_dist(focus_dist_) {}
+
+    rt_camera_desc desc() const {
+        rt_camera_desc d{};
+        for (int a = 0; a < 3; a++) { d.lookfrom[a] = look_from[a]; d.lookat[a] = look_at[a]; d.vup[a] = vup[a]; }
         d.vfov = vfov; d.aspect = aspect_ratio; d.aperture = aperture; d.focus_dist = focus_dist;
+        return d;
+    }
+    // cuda/camera.h:42-57.  Nothing is cached on the host (rt_set_camera derives u, v, w and the
+    // viewport from the descriptor), so this only hands out the descriptor of the current pose.
+    rt_camera_desc compute_camera_scene() const { return desc(); }
+
+    void translate_camera(float x, float y, float z) {               // cuda/camera.h:59-63
+        look_from = point3((float)look_from[0] + x, (float)look_from[1] + y, (float)look_from[2] + z);
+    }
+    void rotate_camera_x(float new_x_angle) { turn(0, new_x_angle, 0, 1); }    // cuda/camera.h:69-81: the xy-plane
+    void rotate_camera_y(float new_y_angle) {                                   // cuda/camera.h:87-99: the xz-plane
+        float c, s;
+        delta(1, new_y_angle, c, s);
+        const float x = (float)look_from[0], z = (float)look_from[2];
+        const float nx = mul(x, c) + mul(z, s), nz = mul(z, c) - mul(x, s);
+        look_from = point3(nx, look_from[1], nz);
+    }
+    void rotate_camera_z(float new_z_angle) { turn(2, new_z_angle, 1, 2); }    // cuda/camera.h:105-117: the yz-plane
+
+private:
+    // a single-precision product, rounded once, which no compiler setting can fuse into an addition
+    static float mul(float a, float b) { return (float)((double)a * (double)b); }
+    // cosine and sine of (new angle - current angle), cuda/utils.h:17 in float; records the new angle
+    void delta(int which, float new_angle, float& c, float& s) {
+        const float d_angle = new_angle - (float)angles[which];
+        const float d_rads = mul(d_angle, 3.1415926535897932385f) / 180.0f;
+        c = (float)std::cos((double)d_rads); s = (float)std::sin((double)d_rads);
+        angles.e[which] = new_angle;
+    }
+    void turn(int which, float new_angle, int i, int j) {
+        float c, s;
+        delta(which, new_angle, c, s);
+        const float a = (float)look_from[i], b = (float)look_from[j];
+        const float na = mul(a, c) - mul(b, s), nb = mul(a, s) + mul(b, c);
+        look_from.e[i] = na; look_from.e[j] = nb;
     }
 };
+
+// cuda/main.cu:206-217
+inline void rotate_scene(camera& cam, float new_x_angle, float new_y_angle, float new_z_angle) {
+    if (new_x_angle != (float)cam.angles.x()) cam.rotate_camera_x(new_x_angle);
+    if (new_y_angle != (float)cam.angles.y()) cam.rotate_camera_y(new_y_angle);
+    if (new_z_angle != (float)cam.angles.z()) cam.rotate_camera_z(new_z_angle);
+}
+// cuda/main.cu:220-279: the camera of frame `frame`, given the camera of the frame before it.
+inline void update_scene(camera& cam, int frame) {
+    const float ax = (float)cam.angles.x(), ay = (float)cam.angles.y(), az = (float)cam.angles.z();
+    if (frame == 0) {
+    } else if (frame < 200) {
+        rotate_scene(cam, ax, ay + 0.125f, az);
+    } else if (frame < 400) {
+        rotate_scene(cam, ax, ay - 0.125f, az);
+    } else if (frame < 500) {
+        rotate_scene(cam, ax + 0.125f, ay, az);
+        cam.translate_camera(-0.025f, 0.025f, 0.0f);
+    } else if (frame < 600) {
+        rotate_scene(cam, ax - 0.125f, ay, az);
+        cam.translate_camera(0.025f, -0.025f, 0.0f);
+    }
+    (void)cam.compute_camera_scene();
+}
 
 // ---- flattening ------------------------------------------------------------------------------
 struct flat_scene {
@@ -263,7 +341,7 @@ public:
         rt_scene_desc d = f.desc(background, bg, accel);
         check(rt_upload_scene(ctx_, &d), "rt_upload_scene");
     }
-    void set_camera(const camera& cam) { check(rt_set_camera(ctx_, &cam.d), "rt_set_camera"); }
+    void set_camera(const camera& cam) { const rt_camera_desc d = cam.desc(); check(rt_set_camera(ctx_, &d), "rt_set_camera"); }
 
     // Whole frame into host memory: float4 per pixel, row 0 = bottom row, rgb = radiance sums.
     std::vector<float> render(int width, int height, int samples_per_pixel, int ray_bounce_limit, uint64_t seed = 1) {

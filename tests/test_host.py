@@ -124,3 +124,34 @@ def test_cpp_facade_flattens_instances_like_the_python_facade(tmp_path):
         for i in range(flat.xform.shape[0]):
             np.testing.assert_allclose([float(x) for x in lines.pop(0).split()], flat.xform[i], rtol=0, atol=1e-12)
     assert not lines
+
+
+def test_cpp_facade_walks_the_camera_path_like_the_python_facade(tmp_path):
+    """cuda/camera.h:29-117 and cuda/main.cu:206-279 in include/rt_scene.hpp against
+    raytrace_amd/scene.py: the same 600 camera states, to the last bit of their floats."""
+    import subprocess
+    from raytrace_amd import scene as S
+    exe = tmp_path / "camera_path_dump"
+    subprocess.run(["g++", "-std=c++17", "-O2", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "cpp", "camera_path_dump.cpp"), "-o", str(exe)], check=True)
+    lines = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines()
+    assert len(lines) == 601
+    cam = S.camera((450, 278, 200), (0, 278, 555), (0, 1, 0), 40.0, 16 / 9, 0.0, 10.0, angles=(0, 0, 0))
+    moved = 0
+    for frame in range(600):
+        S.update_scene(cam, frame)
+        v = lines[frame].split()
+        assert int(v[0]) == frame
+        got = np.array([float(x) for x in v[1:]]).astype(np.float32)          # nine digits identify a float
+        want = np.array([*cam.compute_camera_scene()["lookfrom"], *cam.angles])
+        assert np.array_equal(want, want.astype(np.float32))                  # the path is walked in single precision
+        assert np.array_equal(got, want.astype(np.float32)), (frame, got, want)
+        moved += frame > 0 and lines[frame].split()[1:4] != lines[frame - 1].split()[1:4]
+    assert moved == 599
+    c2 = S.rtiow_camera(1.5)
+    c2.rotate_camera_z(33.0)
+    c2.rotate_camera_x(-12.5)
+    c2.translate_camera(0.1, 0.2, 0.3)
+    c2.rotate_camera_y(400.0)
+    got = np.array([float(x) for x in lines[600].split()[1:]]).astype(np.float32)
+    assert np.array_equal(got, np.array([*c2.look_from, *c2.angles]).astype(np.float32)), (got, c2.look_from, c2.angles)
