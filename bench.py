@@ -1,14 +1,30 @@
 #!/usr/bin/env python3
-"""Headline benchmark: Mrays/s and ms/frame of the RTIOW scene (the reference's default world,
-487 spheres) at 1920x1080, 100 samples per pixel, depth 50, on N MI355X of one node.
+"""Benchmark of the render path on N MI355X of one node: Mrays/s and ms per frame.
 
-A step is one frame.  With N > 1 (one process per GPU, launched by torch.distributed.run) the
-frame is split into interleaved 4-row tiles, each rank renders its tiles and the partial
-framebuffers are gathered on rank 0 over RCCL, inside the timed region.  Two frames are in flight:
-frame k+1 is launched (second stream, its own framebuffer) before frame k is gathered, so the
-timed K steps are K complete frames, rendered and gathered, at the throughput a frame sequence
-gets; the time of one launch from start to end is reported beside it (roofline.kernel_ms).
-A ray is one closest-hit query (main.cc:18), counted on the device.
+    python bench.py                          headline: --config c2 on one GPU
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N
+
+--config   workload (a step is one frame)                                        default partition
+  c2       RTIOW random spheres (the reference's default world, 487 spheres),     tiles
+           1920x1080 @100 spp, depth 50   [the configuration the metric is quoted on]
+  c3       Cornell box (rects + diffuse_light), 1920x1080 @1000 spp                tiles
+  c4       BVH stress: 10^6 spheres, checker and image textures, 3840x2160 @64     tiles
+  c5       camera path (cuda/main.cu:220-279) over the RTIOW scene,                frames+samples
+           1920x1080 @256 spp, a different camera and seed every step
+
+--partition (N > 1)
+  tiles            rank g renders the interleaved 4-row tiles g, g+N, ...; rank 0 gathers the
+                   partial framebuffers over RCCL inside the timed region
+  samples          rank g renders the whole frame for its share of the samples as integer sums
+                   (RT_FLAG_FIXED_SUMS); an int64 RCCL reduce to rank 0 and rt_resolve_sums give
+                   the frame, bit for bit the single-GPU one
+  frames+samples   (c5) frames are dealt to the ranks in rounds of N, no exchange; the frames of
+                   a last, incomplete round are sample-split over all ranks as above
+
+Two frames are in flight: frame k+1 is launched (second stream, its own context and buffer)
+before frame k is collected, so the timed K steps are K complete frames at the throughput a frame
+sequence gets; the time of one launch alone, start to end, is reported beside it
+(roofline.kernel_ms).  A ray is one closest-hit query (main.cc:18), counted on the device.
 
 Prints ONE JSON line on rank 0.
 """
@@ -21,7 +37,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-W, H, SPP, DEPTH, SEED, TILE_ROWS = 1920, 1080, 100, 50, 1, 4
+TILE_ROWS = 4
 PEAK_FP32_TFLOPS = 157.3          # MI355X FP32 vector peak (256 CU x 128 lanes x 2 x 2.4 GHz)
 
 # algorithmic flops per unit of work, fixed constants: sphere test 25 (+24 when a root is
@@ -37,11 +53,12 @@ def executed_flops(st):
             misses * F_MISS + st["samples"] * F_CAMERA)
 
 
-def measured_traffic():
+def measured_traffic(config):
     """HBM bytes per render launch from the committed PMC passes (FETCH_SIZE / WRITE_SIZE are
     collected with rocprofv3 in runs of their own, so they cannot be read inside this process)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "hbm_traffic.json")))
+    name = "hbm_traffic.json" if config == "c2" else f"{config}_hbm_traffic.json"
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", name)))
     if not files:
         return None
     try:
@@ -50,52 +67,113 @@ def measured_traffic():
         return None
 
 
-def cpu_baseline():
-    """The reference's own main.cc (compiled into oracle/_ref) on one host core, on a bounded
-    sample of the same frame: every 3rd pixel of every 3rd row, 16 spp (about 11 s), glibc rand() like the
-    original binary.  Falls back to the C restatement when the compiled reference is absent."""
-    import numpy as np
+class Workload:
+    """Scene, camera and frame size of one --config."""
+
+    def __init__(self, name, spp=None):
+        import numpy as np
+        from raytrace_amd import api, scene as S
+        self.name = name
+        self.depth, self.seed = 50, 1
+        self.accel = api.RT_ACCEL_BVH
+        self.path = False                       # the camera moves from step to step
+        if name in ("c2", "c5"):
+            self.W, self.H, self.spp = 1920, 1080, 100 if name == "c2" else 256
+            self.flat = S.flatten(S.rtiow_scene())
+            self.camera = S.rtiow_camera(float(np.float32(self.W / self.H)))
+            self.n_spheres, self.n_rects = 487, 0
+            self.path = name == "c5"
+            self.label = ("configs[1]: RTIOW random-spheres scene (the reference's default world, 487 spheres, "
+                          "g++ build) 1920x1080 @100spp depth 50" if name == "c2" else
+                          "configs[4]: camera-path sequence (cuda/main.cu:220-279) over the RTIOW scene, "
+                          "1920x1080 @256spp depth 50, one frame per step")
+        elif name == "c3":
+            self.W, self.H, self.spp = 1920, 1080, 1000
+            self.flat = S.flatten(S.cornell_scene(), background=S.RT_BG_SOLID, bg_color=(0, 0, 0))
+            self.camera = S.cornell_camera(float(np.float32(self.W / self.H)))
+            self.n_spheres, self.n_rects = 2, 6
+            self.accel = api.RT_ACCEL_AUTO
+            self.label = ("configs[2]: Cornell box (5 walls + diffuse_light rect, glass and metal r=30 spheres) "
+                          "1920x1080 @1000spp depth 50")
+        elif name == "c4":
+            self.W, self.H, self.spp = 3840, 2160, 64
+            self.flat = S.stress_flat(1_000_000, seed=42)
+            self.camera = S.stress_camera(float(np.float32(self.W / self.H)))
+            self.n_spheres, self.n_rects = 1_000_000, 0
+            self.label = ("configs[3]: BVH stress scene, 10^6 random spheres with checker and image textures, "
+                          "3840x2160 @64spp depth 50 (host-built binned-SAH tree)")
+        else:
+            raise SystemExit(f"unknown config {name}")
+        if spp:
+            self.spp = spp
+            self.label += f" [--spp {spp}]"
+
+    def bruteforce_flops_per_ray(self):
+        """What the reference's linear scan (sceneobject_list.h:26-39) spends on a ray."""
+        return self.n_spheres * F_SPHERE + self.n_rects * F_RECT + 70
+
+    def camera_of_step(self, k):
+        """c5: the camera of frame k (frames follow each other; steps are dealt in order)."""
+        from raytrace_amd import scene as S
+        if not self.path:
+            return self.camera.desc(), self.seed
+        if not hasattr(self, "_walk"):
+            self._walk, self._walk_frame = S.rtiow_camera(self.camera.aspect_ratio), -1
+        if k < self._walk_frame:                 # an earlier frame again: walk from the start
+            self._walk, self._walk_frame = S.rtiow_camera(self.camera.aspect_ratio), -1
+        while self._walk_frame < k:
+            self._walk_frame += 1
+            S.update_scene(self._walk, self._walk_frame)
+        return self._walk.desc(), self.seed + k
+
+
+def cpu_baseline(wl):
+    """The CPU side of the same workload on the host cores of this box, on a bounded sample.
+    c2 / c5 (spheres only): the reference's own main.cc (compiled into oracle/_ref), one core,
+    glibc rand() like the original binary.  c3 / c4 use features main.cc lacks: the C restatement
+    (linear scan, double precision) on the job's host threads."""
     from oracle.pyoracle import Oracle, Reference
     from raytrace_amd import scene as S
-    aspect = float(np.float32(W / H))
-    sample = f"{W}x{H} frame, every 3rd pixel of every 3rd row, 16 spp, depth {DEPTH}, 1 thread"
-    if Reference.available():
+    W, H = wl.W, wl.H
+    cam = wl.camera.desc()
+    if wl.name in ("c2", "c5") and Reference.available():
         ref = Reference()
         ref.load_scene(S.rtiow_records())
-        ref.set_camera((6, 3, -13), (0, 0, 0), (0, 1, 0), 20.0, aspect, 0.1, 10.0)
+        ref.set_camera(cam["lookfrom"], cam["lookat"], cam["vup"], cam["vfov"], cam["aspect"], cam["aperture"], cam["focus_dist"])
         t0 = time.perf_counter()
-        _, rays = ref.render_libc(W, H, 16, DEPTH, step=(3, 3))
+        _, rays = ref.render_libc(W, H, 16, wl.depth, step=(3, 3))
         dt = time.perf_counter() - t0
-        kind = "reference"
-    else:
-        orc = Oracle("f64")
-        flat = S.flatten(S.rtiow_scene())
-        cam = orc.camera((6, 3, -13), (0, 0, 0), (0, 1, 0), 20.0, aspect, 0.1, 10.0)
-        t0 = time.perf_counter()
-        _, rays = orc.render(flat, cam, W, H, 16, DEPTH, SEED, step=(3, 3), threads=1)
-        dt = time.perf_counter() - t0
-        kind = "port"
-    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": 1, "kind": kind, "sample": sample,
+        return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "reference",
+                "sample": f"{W}x{H} frame, every 3rd pixel of every 3rd row, 16 spp, depth {wl.depth}, 1 thread",
+                "seconds": dt, "rays": rays}
+    orc = Oracle("f64")
+    threads = 1 if wl.name in ("c2", "c5") else max(1, min(16, os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16"))))
+    step, spp = {"c2": ((3, 3), 16), "c5": ((3, 3), 16), "c3": ((2, 2), 16), "c4": ((40, 40), 1)}[wl.name]
+    cd = orc.camera(cam["lookfrom"], cam["lookat"], cam["vup"], cam["vfov"], cam["aspect"], cam["aperture"], cam["focus_dist"])
+    t0 = time.perf_counter()
+    _, rays = orc.render(wl.flat, cd, W, H, spp, wl.depth, wl.seed, step=step, threads=threads)
+    dt = time.perf_counter() - t0
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": f"{W}x{H} frame, every {step[0]}th pixel of every {step[1]}th row, {spp} spp, depth {wl.depth}, "
+                      f"{threads} thread(s), linear scan over {wl.flat.n_prims} primitives in double",
             "seconds": dt, "rays": rays}
 
 
-def cpu_baseline_all_cores():
-    """The same sample on the host cores this job may use (16 per GPU on the test boxes), with the
+def cpu_baseline_all_cores(wl):
+    """c2: the same sample on the host cores this job may use (16 per GPU on the test boxes), with the
     C restatement: the reference itself cannot run on several threads (utils.h:25 draws from the
     process-wide rand()), the restatement draws from keyed streams and splits rows over OpenMP
     threads."""
-    import numpy as np
     from oracle.pyoracle import Oracle
-    from raytrace_amd import scene as S
     threads = max(1, min(16, os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16"))))
     orc = Oracle("f64")
-    flat = S.flatten(S.rtiow_scene())
-    cam = orc.camera((6, 3, -13), (0, 0, 0), (0, 1, 0), 20.0, float(np.float32(W / H)), 0.1, 10.0)
+    cam = wl.camera.desc()
+    cd = orc.camera(cam["lookfrom"], cam["lookat"], cam["vup"], cam["vfov"], cam["aspect"], cam["aperture"], cam["focus_dist"])
     t0 = time.perf_counter()
-    _, rays = orc.render(flat, cam, W, H, 16, DEPTH, SEED, step=(2, 2), threads=threads)
+    _, rays = orc.render(wl.flat, cd, wl.W, wl.H, 16, wl.depth, wl.seed, step=(2, 2), threads=threads)
     dt = time.perf_counter() - t0
     return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
-            "sample": f"{W}x{H} frame, every 2nd pixel of every 2nd row, 16 spp, depth {DEPTH}, {threads} threads",
+            "sample": f"{wl.W}x{wl.H} frame, every 2nd pixel of every 2nd row, 16 spp, depth {wl.depth}, {threads} threads",
             "seconds": dt, "rays": rays}
 
 
@@ -104,101 +182,172 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", choices=["c2", "c3", "c4", "c5"], default="c2")
+    ap.add_argument("--partition", choices=["tiles", "samples", "frames+samples"], default=None,
+                    help="how N > 1 ranks share the work (default: tiles; c5: frames+samples)")
+    ap.add_argument("--spp", type=int, default=None, help="override the config's samples per pixel (rehearsals)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--accel", choices=["bvh", "list"], default="bvh")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
-                    help="gloo: rehearse the N-rank path on fewer GPUs (ranks share devices, shards gathered via host)")
+                    help="gloo: rehearse the N-rank path on fewer GPUs (ranks share devices, shards exchanged via host)")
     ap.add_argument("--frames-in-flight", type=int, choices=[1, 2], default=2,
-                    help="2: frame k+1 is launched on a second stream before frame k is gathered; "
+                    help="2: frame k+1 is launched on a second stream before frame k is collected; "
                          "1: one frame at a time (what the kernel-trace profile is taken with)")
     ap.add_argument("--check", action="store_true",
-                    help="rank 0 also renders the whole frame alone and compares it bit for bit with the gathered one")
+                    help="rank 0 also renders every timed frame alone and compares it bit for bit with the assembled one")
     args = ap.parse_args()
 
     import numpy as np
     import torch
     import torch.distributed as dist
-    from raytrace_amd import api, dist as rdist, scene as S
+    from raytrace_amd import api, dist as rdist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    partition = args.partition or ("frames+samples" if args.config == "c5" else "tiles")
+    if partition == "frames+samples" and args.config != "c5":
+        raise SystemExit("--partition frames+samples is the camera-path config's (c5)")
     device = local_rank if args.backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(device)
+    comm_dev = "cuda" if args.backend == "nccl" else "cpu"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", device))
         else:
             dist.init_process_group("gloo")
-        # the first gather on a communicator sets up its peer connections: done here, untimed,
+        # the first collectives on a communicator set up its peer connections: done here, untimed,
         # whatever --warmup is
-        probe = torch.zeros(16, device="cuda" if args.backend == "nccl" else "cpu")
+        probe = torch.zeros(16, device=comm_dev)
         dist.gather(probe, [torch.empty_like(probe) for _ in range(world)] if rank == 0 else None, dst=0)
+        probe_i = torch.zeros(16, dtype=torch.int64, device=comm_dev)
+        dist.reduce(probe_i, dst=0)
         dist.barrier()
 
+    wl = Workload(args.config, args.spp)
+    W, H, SPP, DEPTH = wl.W, wl.H, wl.spp, wl.depth
+    accel = api.RT_ACCEL_LIST if args.accel == "list" else wl.accel
+
     # Two frames in flight: frame k+1 is launched on a second stream (its own context, counters
-    # and framebuffer) before frame k is gathered, so it starts in the tail of frame k, where the
+    # and framebuffer) before frame k is collected, so it starts in the tail of frame k, where the
     # last long paths leave most of the chip idle, and renders while frame k's shards travel.
-    # The gather itself stays on torch's current stream.  There are three framebuffers for the
+    # The collectives stay on torch's current stream.  There are three framebuffers for the
     # two contexts: the gather of frame k finds room on the chip only in the tail of frame k+1
     # (its kernels wait for workgroup slots like any other), and with a third buffer frame k+2
     # does not wait for it.
     n_ctx = args.frames_in_flight
     n_buf = 3 if n_ctx == 2 else 1
-    main = torch.cuda.current_stream()
+    main_stream = torch.cuda.current_stream()
     streams = [torch.cuda.Stream() for _ in range(n_ctx)]
-    aspect = float(np.float32(W / H))
-    flat = S.flatten(S.rtiow_scene())
     ctxs = []
     for s in streams:
         c = api.Context(device)
         c.set_stream(s.cuda_stream)
-        c.upload_scene(flat, accel=api.RT_ACCEL_BVH if args.accel == "bvh" else api.RT_ACCEL_LIST)
-        c.set_camera((6, 3, -13), (0, 0, 0), (0, 1, 0), 20.0, aspect, 0.1, 10.0)    # main.cc:100-106
+        c.upload_scene(wl.flat, accel=accel)
+        c.set_camera(**wl.camera.desc())
         ctxs.append(c)
     ctx = ctxs[0]
+    build_ms = ctx.stats()["build_ms"]
+    # resolve / quantise of a reduced frame run on torch's stream, behind the reduce (a context
+    # without a scene: those two calls need none)
+    post = api.Context(device)
+    post.set_stream(main_stream.cuda_stream)
+
+    # How step k is shared out.  mode "tiles": this rank's interleaved row tiles, float image,
+    # gather.  mode "samples": this rank's sample window of the whole frame, integer sums,
+    # reduce + resolve.  mode "own": the whole frame on one rank, nothing exchanged (frame-parallel
+    # rounds of c5; and every step of a single-GPU run).
+    full_rounds = (args.steps // world) * world if partition == "frames+samples" else 0
+
+    def plan(k, n_steps):
+        if world == 1:
+            return "own", 0
+        if partition == "tiles":
+            return "tiles", None
+        if partition == "samples":
+            return "samples", None
+        rounds = (n_steps // world) * world
+        return ("own", k % world) if k < rounds else ("samples", None)
 
     tiles = (TILE_ROWS, rank, world) if world > 1 else (0, 0, 0)
-    max_rows = rdist.max_shard_rows(H, TILE_ROWS, world) if world > 1 else H
-    shards = [torch.zeros((max_rows, W, 4), dtype=torch.float32, device="cuda") for _ in range(n_buf)]
-    shard = shards[0]
-    params = api.Context.params(W, H, SPP, DEPTH, SEED, tiles=tiles)
+    max_rows = rdist.max_shard_rows(H, TILE_ROWS, world) if (world > 1 and partition == "tiles") else H
+    P = api.Context.params
+    fbufs = [torch.zeros((max_rows, W, 4), dtype=torch.float32, device="cuda") for _ in range(n_buf)]
+    ibufs = [torch.zeros((H, W, 4), dtype=torch.int64, device="cuda") for _ in range(n_buf)] if (world > 1 and partition != "tiles") else None
+    rgb8 = [torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda") for _ in range(n_buf)] if wl.path else None
+    my_begin, my_count = rdist.sample_window(SPP, rank, world)
     rendered = [torch.cuda.Event() for _ in range(n_buf)]    # the frame in buffer i is complete
-    consumed = [torch.cuda.Event() for _ in range(n_buf)]    # buffer i has been gathered and may be overwritten
+    consumed = [torch.cuda.Event() for _ in range(n_buf)]    # buffer i has been collected and may be overwritten
     torch.cuda.synchronize()
     for i in range(n_buf):
-        consumed[i].record(main)
+        consumed[i].record(main_stream)
 
-    def launch(k, ev=None):
+    def launch(k, n_steps, ev=None):
         c, i = k % n_ctx, k % n_buf                          # launches of one context run in stream order
+        mode, owner = plan(k, n_steps)
         streams[c].wait_event(consumed[i])
         if ev:
             ev[0].record(streams[c])
-        ctxs[c].render(params, shards[i].data_ptr())
+        if mode != "own" or owner == rank:
+            cam, seed = wl.camera_of_step(k)
+            if wl.path:
+                ctxs[c].set_camera(**cam)
+            if mode == "tiles":
+                ctxs[c].render(P(W, H, SPP, DEPTH, seed, tiles=tiles), fbufs[i].data_ptr())
+            elif mode == "samples":
+                if my_count > 0:
+                    ctxs[c].render(P(W, H, my_count, DEPTH, seed, sample_begin=my_begin, flags=api.RT_FLAG_FIXED_SUMS), ibufs[i].data_ptr())
+                else:
+                    with torch.cuda.stream(streams[c]):
+                        ibufs[i].zero_()
+            else:
+                ctxs[c].render(P(W, H, SPP, DEPTH, seed), fbufs[i].data_ptr())
+                if wl.path:                                  # the sequence driver's write_color step (cuda/main.cu:587)
+                    ctxs[c].quantize(fbufs[i].data_ptr(), W * H, SPP, rgb8[i].data_ptr())
         if ev:
             ev[1].record(streams[c])
         rendered[i].record(streams[c])
 
-    def collect(k):
-        i = k % n_buf
-        main.wait_event(rendered[i])
-        if args.backend == "gloo" and world > 1:
-            frame = rdist.gather_frame(shards[i].cpu(), H, TILE_ROWS, rank, world)
-        else:
-            frame = rdist.gather_frame(shards[i], H, TILE_ROWS, rank, world)
-        consumed[i].record(main)
+    def collect(k, n_steps):
+        """Returns the finished frame where this rank holds it (float image; c5: RGB8), else None."""
+        c, i = k % n_ctx, k % n_buf
+        mode, owner = plan(k, n_steps)
+        main_stream.wait_event(rendered[i])
+        frame = None
+        if mode == "tiles":
+            frame = rdist.gather_frame(fbufs[i].cpu() if args.backend == "gloo" else fbufs[i], H, TILE_ROWS, rank, world)
+        elif mode == "samples":
+            if args.backend == "gloo":
+                host = ibufs[i].cpu()
+                rdist.reduce_sums(host, rank, world)
+                if rank == 0:
+                    ibufs[i].copy_(host)
+            else:
+                rdist.reduce_sums(ibufs[i], rank, world)
+            if rank == 0:
+                post.resolve_sums(ibufs[i].data_ptr(), W * H, fbufs[i].data_ptr())
+                if wl.path:
+                    post.quantize(fbufs[i].data_ptr(), W * H, SPP, rgb8[i].data_ptr())
+                frame = rgb8[i] if wl.path else fbufs[i][:H]
+        elif owner == rank:
+            frame = rgb8[i] if wl.path else fbufs[i][:H]
+        consumed[i].record(main_stream)
         return frame
 
-    def run(n, events=None):
+    kept = {}                                                # --check: the frames this rank ended up holding
+
+    def run(n, events=None, keep=False):
         frame, launched = None, 0
         for k in range(n):
-            while launched < n and launched < k + n_buf:     # up to n_buf - 1 frames ahead of the gather
-                launch(launched, events[launched] if events else None)
+            while launched < n and launched < k + n_buf:     # up to n_buf - 1 frames ahead of the collect
+                launch(launched, n, events[launched] if events else None)
                 launched += 1
-            frame = collect(k)
+            frame = collect(k, n)
+            if keep and frame is not None:
+                kept[k] = frame.clone()
         return frame
 
     def fence():
@@ -216,102 +365,167 @@ def main():
     fence()
     dt = time.perf_counter() - t0
 
-    if world == 1 and frame is not None:
-        frame = frame.clone()                         # the buffers are rendered into again below
-    st = ctx.stats()                                  # a frame's device counters (all frames equal)
+    if args.check:                                           # the same steps again, untimed, kept
+        run(args.steps, keep=True)
+        torch.cuda.synchronize()
+
+    # rays of the timed region, whole job: every launch's device counter
+    # (a context's counter holds its last launch; all frames of a fixed camera are equal)
+    def rays_of_step(k, n_steps):
+        """Device ray count of this rank's launch for step k (re-rendered alone, untimed)."""
+        mode, owner = plan(k, n_steps)
+        if mode == "own" and owner != rank:
+            return 0
+        launch(k, n_steps)
+        torch.cuda.synchronize()
+        return ctxs[k % n_ctx].stats()["rays"]
+
+    if wl.path:
+        my_rays = sum(rays_of_step(k, args.steps) for k in range(args.steps))
+    else:
+        my_rays = rays_of_step(0, args.steps) * args.steps
+    for i in range(n_buf):
+        consumed[i].record(main_stream)
+
+    # the duration of one launch, start to end.  A launch queued behind the frame before it waits
+    # for that frame's waves to leave the chip, and an event pair around it times the wait with
+    # it: with two frames in flight it is taken from launches that run alone, right after the
+    # timed region (same kernel, same arguments, same stream).
+    lone_step = 0 if plan(0, args.steps)[0] != "own" or plan(0, args.steps)[1] == rank else rank
     if args.frames_in_flight == 2 and args.steps > 1:
-        # A launch queued behind the frame before it waits for that frame's waves to leave the
-        # chip, and an event pair around it times the wait with it.  The duration of one launch,
-        # start to end, is therefore taken from launches that run alone, right after the timed
-        # region: same kernel, same arguments, same stream.
         lone = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 for _ in range(min(args.steps, 5))]
         for ev in lone:
-            launch(0, ev)
+            launch(lone_step, args.steps, ev)
             torch.cuda.synchronize()
         kernel_ms = sum(a.elapsed_time(b) for a, b in lone) / len(lone)
     else:
-        kernel_ms = sum(a.elapsed_time(b) for a, b in events) / max(args.steps, 1)
-    tot = torch.tensor([dt, float(st["rays"]), kernel_ms], dtype=torch.float64,
-                       device="cuda" if args.backend == "nccl" else "cpu")
+        mine = [events[k] for k in range(args.steps) if plan(k, args.steps)[0] != "own" or plan(k, args.steps)[1] == rank]
+        kernel_ms = sum(a.elapsed_time(b) for a, b in mine) / max(len(mine), 1)
+    st = ctxs[lone_step % n_ctx].stats()
+    tot = torch.tensor([dt, float(my_rays), kernel_ms], dtype=torch.float64, device=comm_dev)
     if world > 1:
         mx = tot.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         sm = tot.clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
-        dt, kernel_ms, rays_frame = float(mx[0]), float(mx[2]), float(sm[1])
+        dt, kernel_ms, rays_total = float(mx[0]), float(mx[2]), float(sm[1])
     else:
-        rays_frame = float(st["rays"])
+        rays_total = float(my_rays)
 
-    # executed algorithmic flops of this rank's launch, from the counting build of the same kernel
-    cparams = api.Context.params(W, H, SPP, DEPTH, SEED, tiles=tiles, flags=api.RT_FLAG_COUNTERS)
-    ctx.render(cparams, shard.data_ptr())
+    # executed algorithmic flops of this rank's launch of step `lone_step`, from the counting build
+    # of the same kernel on the same seed
+    mode0, _ = plan(lone_step, args.steps)
+    cam0, seed0 = wl.camera_of_step(lone_step)
+    if wl.path:
+        ctx.set_camera(**cam0)
+    if mode0 == "tiles":
+        cparams = P(W, H, SPP, DEPTH, seed0, tiles=tiles, flags=api.RT_FLAG_COUNTERS)
+    elif mode0 == "samples":
+        cparams = P(W, H, max(my_count, 1), DEPTH, seed0, sample_begin=my_begin, flags=api.RT_FLAG_COUNTERS)
+    else:
+        cparams = P(W, H, SPP, DEPTH, seed0, flags=api.RT_FLAG_COUNTERS)
+    torch.cuda.synchronize()
+    ctx.render(cparams, fbufs[0].data_ptr())
     cst = ctx.stats()
     flops = executed_flops(cst)
-    n_prims = 487
-    brute = cst["rays"] * (n_prims * F_SPHERE + 70)
+    brute = cst["rays"] * wl.bruteforce_flops_per_ray()
+    per_ray = {k: cst[k] / max(cst["rays"], 1) for k in ("box_tests", "sphere_tests", "sphere_hits", "rect_tests", "wide_tests")}
+    # traversal lane utilisation of the counting launch: lane steps / (64 x wave steps)
+    trav_util = cst["phase_clocks"][0] / (64.0 * cst["phase_clocks"][1]) if cst["phase_clocks"][1] else None
 
     # the reference's own closest-hit algorithm (linear scan over all spheres,
     # sceneobject_list.h:26-39) on the same frame: its flop count per ray is fixed, which makes it
     # the like-for-like VALU roofline figure next to the BVH kernel's
     list_mode = None
-    if world == 1 and args.accel == "bvh":
+    if world == 1 and args.accel == "bvh" and args.config == "c2":
         lctx = api.Context(device)
         lctx.set_stream(torch.cuda.current_stream().cuda_stream)
-        lctx.upload_scene(S.flatten(S.rtiow_scene()), accel=api.RT_ACCEL_LIST)
-        lctx.set_camera((6, 3, -13), (0, 0, 0), (0, 1, 0), 20.0, aspect, 0.1, 10.0)
+        lctx.upload_scene(wl.flat, accel=api.RT_ACCEL_LIST)
+        lctx.set_camera(**wl.camera.desc())
         best = None
         for _ in range(3):
-            lctx.render(api.Context.params(W, H, SPP, DEPTH, SEED), shard.data_ptr())
+            lctx.render(P(W, H, SPP, DEPTH, wl.seed), fbufs[0].data_ptr())
             lst = lctx.stats()
             best = lst if best is None or lst["kernel_ms"] < best["kernel_ms"] else best
-        lflops = best["rays"] * (n_prims * F_SPHERE + 70)
+        lflops = best["rays"] * wl.bruteforce_flops_per_ray()
         list_mode = {"kernel_ms": best["kernel_ms"], "mrays_s": best["rays"] / best["kernel_ms"] / 1e3,
                      "achieved": lflops / (best["kernel_ms"] * 1e-3) / 1e12,
                      "frac": lflops / (best["kernel_ms"] * 1e-3) / 1e12 / PEAK_FP32_TFLOPS,
-                     "flops_per_ray": n_prims * F_SPHERE + 70}
+                     "flops_per_ray": wl.bruteforce_flops_per_ray()}
         lctx.close()
 
     frame_ok = None
-    if args.check and rank == 0:
+    if args.check:
+        # each rank checks the frames it ended up holding against its own whole-frame render of the
+        # same step; together the ranks must hold every step exactly once
+        ok = True
         whole = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
-        ctx.render(api.Context.params(W, H, SPP, DEPTH, SEED), whole.data_ptr())
-        torch.cuda.synchronize()
-        frame_ok = bool(torch.equal(whole.cpu(), frame.cpu()))
+        out8 = torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda")
+        for k, got in kept.items():
+            cam, seed = wl.camera_of_step(k)
+            ctx.set_camera(**cam)
+            ctx.render(P(W, H, SPP, DEPTH, seed), whole.data_ptr())
+            if wl.path:
+                ctx.quantize(whole.data_ptr(), W * H, SPP, out8.data_ptr())
+            ctx.stats()
+            want = out8 if wl.path else whole
+            ok = ok and bool(torch.equal(want.cpu(), got.cpu()))
+        held = torch.tensor([len(kept), int(ok)], dtype=torch.int64, device=comm_dev)
+        if world > 1:
+            allh = [torch.zeros_like(held) for _ in range(world)]
+            dist.all_gather(allh, held)
+        else:
+            allh = [held]
+        frame_ok = all(int(h[1]) == 1 for h in allh) and sum(int(h[0]) for h in allh) == args.steps
 
     if rank == 0:
+        if world == 1:
+            how = "single GPU"
+        elif partition == "tiles":
+            how = f"row-tiles x{world}, RCCL gather to rank 0"
+        elif partition == "samples":
+            how = f"sample-split x{world} as integer sums, RCCL int64 reduce to rank 0 + resolve"
+        else:
+            how = (f"frames dealt in rounds of {world} ({full_rounds} of {args.steps} steps), the other "
+                   f"{args.steps - full_rounds} sample-split x{world} (integer sums, int64 reduce)")
         out = {
             "metric": "Mrays/sec (whole node) + ms/frame 1080p@100spp",
-            "value": rays_frame * args.steps / dt / 1e6, "unit": "Mrays/s",
+            "value": rays_total / dt / 1e6, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[1]: RTIOW random-spheres scene (the reference's default world, "
-                                   "487 spheres, g++ build) 1920x1080 @100spp depth 50",
-                       "accel": args.accel, "tile_rows": TILE_ROWS if world > 1 else None,
-                       "partition": f"row-tiles x{world}, RCCL gather to rank 0" if world > 1 else "single GPU",
-                       "rays_per_frame": rays_frame, "lanes_per_pixel": st["lanes_per_pixel"],
+            "config": {"workload": wl.label, "config": args.config, "width": W, "height": H, "spp": SPP,
+                       "accel": args.accel, "tile_rows": TILE_ROWS if (world > 1 and partition == "tiles") else None,
+                       "partition": how,
+                       "rays_per_frame": rays_total / args.steps, "lanes_per_pixel": st["lanes_per_pixel"],
+                       "bvh_depth": st["bvh_depth"], "bvh_nodes": st["bvh_nodes"], "bvh_build_ms": build_ms,
                        "frames_in_flight": args.frames_in_flight if args.steps > 1 else 1},
             "roofline": {"bound": "valu", "achieved": flops / (kernel_ms * 1e-3) / 1e12,
                          "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": flops / (kernel_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS,
-                         "traffic": measured_traffic() if world == 1 and args.accel == "bvh" else None,
+                         "traffic": measured_traffic(args.config) if world == 1 and args.accel == "bvh" else None,
                          "kernel": "render_kernel", "kernel_ms": kernel_ms, "frame_latency_ms": kernel_ms,
-                         "flops_per_launch": flops,
+                         "one_launch_at_a_time_mrays_s": cst["rays"] / kernel_ms / 1e3,
+                         "flops_per_launch": flops, "flops_per_ray": flops / max(cst["rays"], 1),
+                         "tests_per_ray": per_ray, "traversal_lane_utilisation": trav_util,
                          "bruteforce_equivalent_tflops": brute / (kernel_ms * 1e-3) / 1e12,
+                         "bruteforce_flops_per_ray": wl.bruteforce_flops_per_ray(),
                          "linear_scan_kernel": list_mode,
-                         "note": "FP32 VALU-bound path (no dense contraction, ~33 MB of HBM writes per frame); "
-                                 "achieved = executed algorithmic flops of rank 0's launch / kernel_ms, the HIP-event "
-                                 "time of one launch on the stream it is launched on.  With two frames in "
-                                 "flight a launch starts in the tail of the one before it, so ms_per_step "
-                                 "(throughput) is shorter than kernel_ms; kernel_ms is then taken from launches "
-                                 "that run alone right after the timed region (an event pair around a queued "
-                                 "launch would time its wait for the chip as well)"},
+                         "note": "FP32 VALU-bound path (no dense contraction; HBM traffic is the framebuffer and, for c4, "
+                                 "BVH nodes through L2); achieved = executed algorithmic flops of rank 0's launch "
+                                 "(counting build of the same kernel, same seed) / kernel_ms, the HIP-event time of ONE "
+                                 "launch running alone on the stream it is launched on.  value and ms_per_step are the "
+                                 "throughput of the frame sequence: with two frames in flight a launch starts in the tail "
+                                 "of the one before it, so ms_per_step is shorter than kernel_ms; the conservative "
+                                 "one-launch-at-a-time rate is one_launch_at_a_time_mrays_s"},
         }
         if frame_ok is not None:
             out["frame_matches_single_gpu"] = frame_ok
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
-            out["speedup_vs_cpu_1thread"] = out["value"] / out["cpu_baseline"]["value"]
-            out["cpu_baseline_all_cores"] = cpu_baseline_all_cores()
+            out["cpu_baseline"] = cpu_baseline(wl)
+            out["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+            if args.config == "c2":
+                out["speedup_vs_cpu_1thread"] = out["speedup_vs_cpu"]
+                out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(wl)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -3,6 +3,8 @@
 //
 //   g++ -std=c++17 -Iinclude examples/rtiow_main.cpp -Lraytrace_amd -lrt_amd -Wl,-rpath,$PWD/raytrace_amd -o rtiow
 //   ./rtiow scene.txt 1200 800 500 > image.ppm
+//   ./rtiow scene.txt 480 270 1 450 > image_450_low.ppm    (frame 450 of the CUDA driver's camera path,
+//                                                           cuda/main.cu:220-279,557-591)
 //
 // scene.txt holds one sphere per line: cx cy cz r type(0 lambertian,1 metal,2 dielectric) r g b fuzz|ir
 // (the reference's own generate_random_scene depends on its compiler's argument evaluation
@@ -32,15 +34,17 @@ static sceneobject_list load_world(const char* path) {
 }
 
 int main(int argc, char** argv) {
-    if (argc < 2) { std::cerr << "usage: rtiow scene.txt [width height spp]\n"; return 2; }
+    if (argc < 2) { std::cerr << "usage: rtiow scene.txt [width height spp [frame]]\n"; return 2; }
     const int image_width = argc > 2 ? std::atoi(argv[2]) : 1200;
     const int image_height = argc > 3 ? std::atoi(argv[3]) : 800;
     const int samples_per_pixel = argc > 4 ? std::atoi(argv[4]) : 500;
+    const int frame = argc > 5 ? std::atoi(argv[5]) : 0;
     const int ray_bounce_limit = 50;
     const float aspect_ratio = (float)image_width / (float)image_height;
 
     sceneobject_list world = load_world(argv[1]);
     camera cam(point3(6, 3, -13), point3(0, 0, 0), vec3(0, 1, 0), 20, aspect_ratio, 0.1, 10.0);
+    for (int f = 0; f <= frame; f++) update_scene(cam, f);             // cuda/main.cu:564, once per frame up to this one
 
     try {
         renderer gpu(0);

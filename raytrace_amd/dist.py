@@ -25,47 +25,65 @@ def max_shard_rows(height: int, tile_rows: int, world: int) -> int:
     return max(len(shard_row_map(height, tile_rows, g, world)) for g in range(world))
 
 
-_ROW_INDEX_CACHE = {}
+_GATHER_INDEX_CACHE = {}
 
 
-def _row_index(height, tile_rows, g, world, device):
+def gather_index(height: int, tile_rows: int, world: int, max_rows: int | None = None) -> np.ndarray:
+    """For every global row, its position in the ranks' packed shards laid end to end
+    (rank g's shard starts at g * max_rows): the whole un-interleave is one index_select."""
+    if max_rows is None:
+        max_rows = max_shard_rows(height, tile_rows, world)
+    index = np.empty(height, dtype=np.int64)
+    for g in range(world):
+        rows = shard_row_map(height, tile_rows, g, world)
+        index[rows] = g * max_rows + np.arange(len(rows))
+    return index
+
+
+def _gather_index(height, tile_rows, world, max_rows, device):
     import torch
-    key = (height, tile_rows, g, world, str(device))
-    if key not in _ROW_INDEX_CACHE:
-        _ROW_INDEX_CACHE[key] = torch.as_tensor(shard_row_map(height, tile_rows, g, world), device=device)
-    return _ROW_INDEX_CACHE[key]
+    key = (height, tile_rows, world, max_rows, str(device))
+    if key not in _GATHER_INDEX_CACHE:
+        _GATHER_INDEX_CACHE[key] = torch.as_tensor(gather_index(height, tile_rows, world, max_rows), device=device)
+    return _GATHER_INDEX_CACHE[key]
 
 
 def gather_frame(shard, height: int, tile_rows: int, rank: int, world: int, dst: int = 0, group=None):
-    """shard: torch tensor [max_shard_rows, W, C] (rows past this rank's count are padding).
-    Returns the assembled [height, W, C] frame on `dst`, None elsewhere."""
+    """shard: torch tensor [max_shard_rows, W, C] (rows past this rank's count are padding), the
+    same shape on every rank.  Returns the assembled [height, W, C] frame on `dst`, None elsewhere.
+    The shards arrive side by side in one buffer and one precomputed row index puts every row in
+    its place."""
     import torch
     import torch.distributed as dist
 
     if world == 1:
         return shard[:height]
-    try:
-        bufs = [torch.empty_like(shard) for _ in range(world)] if rank == dst else None
-        dist.gather(shard, bufs, dst=dst, group=group)
-    except (RuntimeError, NotImplementedError):
-        # a backend without gather: every rank receives every shard instead
-        flat = torch.empty((world,) + tuple(shard.shape), dtype=shard.dtype, device=shard.device)
-        dist.all_gather_into_tensor(flat, shard, group=group)
-        bufs = list(flat.unbind(0))
+    flat = torch.empty((world,) + tuple(shard.shape), dtype=shard.dtype, device=shard.device) if rank == dst else None
+    dist.gather(shard, list(flat.unbind(0)) if rank == dst else None, dst=dst, group=group)
     if rank != dst:
         return None
-    frame = torch.empty((height,) + tuple(shard.shape[1:]), dtype=shard.dtype, device=shard.device)
-    for g in range(world):
-        rows = _row_index(height, tile_rows, g, world, shard.device)
-        frame[rows] = bufs[g][: rows.numel()]
-    return frame
+    index = _gather_index(height, tile_rows, world, shard.shape[0], shard.device)
+    return flat.view((world * shard.shape[0],) + tuple(shard.shape[1:])).index_select(0, index)
 
 
-def reduce_frame(partial, rank: int, world: int, dst: int = 0, group=None):
-    """Sample-split: every rank rendered the whole frame for its own sample range
-    (sample_begin = rank * spp); the float4 sums add up on `dst`."""
+def reduce_sums(partial, rank: int, world: int, dst: int = 0, group=None):
+    """Sample-split: every rank rendered the whole frame for its own sample window (sample_begin)
+    with RT_FLAG_FIXED_SUMS, `partial` holding the [H, W, 4] integer image as int64 (r, g, b sums in
+    32.32 fixed point, sample count).  Integer addition is exact and order-free, so the sum on
+    `dst` is bit for bit what one GPU accumulates for all the samples, whatever the reduction
+    tree; rt_resolve_sums turns it into the float frame.  Reduces in place."""
+    import torch
     import torch.distributed as dist
 
+    if partial.dtype != torch.int64:
+        raise TypeError("reduce_sums takes the RT_FLAG_FIXED_SUMS image as int64")
     if world > 1:
         dist.reduce(partial, dst=dst, op=dist.ReduceOp.SUM, group=group)
     return partial if rank == dst else None
+
+
+def sample_window(spp: int, rank: int, world: int):
+    """(sample_begin, count) of `rank`'s share of `spp` samples: windows differ by at most one."""
+    base, extra = divmod(spp, world)
+    begin = rank * base + min(rank, extra)
+    return begin, base + (1 if rank < extra else 0)

@@ -34,4 +34,13 @@ def test_cpp_driver_matches_python_host(tmp_path, oracle):
     assert np.array_equal(got, want)
     # and the text the Python writer produces is byte-identical to the C++ driver's
     assert ppm.p3_bytes(want.astype(np.uint8)) == out.stdout
+    # frame 450 of the camera path, walked by the C++ facade's update_scene and by the Python one
+    out = subprocess.run([EXE, str(scene_txt), str(W), str(H), str(spp), "450"], capture_output=True, check=True, timeout=120)
+    cam = S.rtiow_camera(float(np.float32(W / H)))
+    for f in range(451):
+        S.update_scene(cam, f)
+    ctx.set_camera(**cam.desc())
+    img = ctx.render_host(api.Context.params(W, H, spp, 50, 1))
+    want = oracle.write_color(img[..., :3].astype(np.float64).reshape(-1, 3), spp).reshape(H, W, 3)
+    assert ppm.p3_bytes(want.astype(np.uint8)) == out.stdout
     ctx.close()
