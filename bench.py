@@ -148,13 +148,14 @@ def cpu_baseline(wl):
                 "seconds": dt, "rays": rays}
     orc = Oracle("f64")
     threads = 1 if wl.name in ("c2", "c5") else max(1, min(16, os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16"))))
-    step, spp = {"c2": ((3, 3), 16), "c5": ((3, 3), 16), "c3": ((2, 2), 16), "c4": ((40, 40), 1)}[wl.name]
+    step, spp = {"c2": ((3, 3), 16), "c5": ((3, 3), 16), "c3": ((1, 1), 256), "c4": ((20, 20), 1)}[wl.name]
     cd = orc.camera(cam["lookfrom"], cam["lookat"], cam["vup"], cam["vfov"], cam["aspect"], cam["aperture"], cam["focus_dist"])
     t0 = time.perf_counter()
     _, rays = orc.render(wl.flat, cd, W, H, spp, wl.depth, wl.seed, step=step, threads=threads)
     dt = time.perf_counter() - t0
     return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
-            "sample": f"{W}x{H} frame, every {step[0]}th pixel of every {step[1]}th row, {spp} spp, depth {wl.depth}, "
+            "sample": f"{W}x{H} frame, " + ("every pixel" if step == (1, 1) else f"every {step[0]}th pixel of every {step[1]}th row") +
+                      f", {spp} spp, depth {wl.depth}, "
                       f"{threads} thread(s), linear scan over {wl.flat.n_prims} primitives in double",
             "seconds": dt, "rays": rays}
 

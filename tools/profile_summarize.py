@@ -1,6 +1,6 @@
-"""Turns the output of tools/profile_round.sh into the small files kept under profiles/.
+"""Turns the output of tools/profile_config.sh into the small files kept under profiles/.
 
-usage: python tools/profile_summarize.py gpurun_out/<dir> profiles/<round>
+usage: python tools/profile_summarize.py <c2|c3|c4|c5> gpurun_out/<dir> profiles/<round>
 """
 import collections
 import csv
@@ -10,16 +10,18 @@ import os
 import shutil
 import sys
 
-src, dst = sys.argv[1], sys.argv[2]
+cfg, src, dst = sys.argv[1], sys.argv[2], sys.argv[3]
 os.makedirs(dst, exist_ok=True)
 
 stats = glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv"))
 if stats:
-    shutil.copy(stats[0], os.path.join(dst, "c2_kernel_stats.csv"))
+    shutil.copy(stats[0], os.path.join(dst, f"{cfg}_kernel_stats.csv"))
+bench = None
 line = [l for l in open(os.path.join(src, "bench_traced.json")) if l.startswith("{")]
 if line:
-    with open(os.path.join(dst, "c2_bench.json"), "w") as f:
+    with open(os.path.join(dst, f"{cfg}_bench.json"), "w") as f:
         f.write(line[-1])
+    bench = json.loads(line[-1])
 
 per_kernel = collections.defaultdict(lambda: collections.defaultdict(lambda: collections.defaultdict(float)))
 for path in glob.glob(os.path.join(src, "pmc_*", "*", "*counter_collection.csv")):
@@ -33,26 +35,51 @@ out = {}
 for name, ctrs in per_kernel.items():
     out[name] = {k: sum(v.values()) / len(v) for k, v in sorted(ctrs.items())}
     out[name]["launches_per_pass"] = max(len(v) for v in ctrs.values())
-with open(os.path.join(dst, "c2_pmc_per_launch.json"), "w") as f:
-    json.dump(out, f, indent=1)
 
-main = [n for n in out if "render_kernel<false, true, false, 1, false>" in n]      # plain, LDS-resident BVH, no rects
+# the timed kernel: the plain build (first template argument false) with the most launches
+plain = [n for n in out if "render_kernel<false" in n and (cfg != "c2" or "1, false>" in n)]
+main = max(plain, key=lambda n: out[n]["launches_per_pass"]) if plain else None
 if main:
-    c = out[main[0]]
-    fetch_kb, write_kb = c.get("FETCH_SIZE", 0.0), c.get("WRITE_SIZE", 0.0)
+    c = out[main]
+    g = lambda k: c.get(k, 0.0)
+    derived = {"kernel": main}
+    if g("SQ_ACTIVE_INST_VALU"):
+        derived["valu_lanes_active_of_64"] = g("SQ_THREAD_CYCLES_VALU") / g("SQ_ACTIVE_INST_VALU")
+    if g("SQ_WAVE_CYCLES"):
+        derived["wait_any_fraction_of_wave_cycles"] = g("SQ_WAIT_ANY") / g("SQ_WAVE_CYCLES") if g("SQ_WAIT_ANY") else None
+        derived["wait_inst_any_fraction_of_wave_cycles"] = g("SQ_WAIT_INST_ANY") / g("SQ_WAVE_CYCLES")
+    if g("TCC_HIT_sum") + g("TCC_MISS_sum"):
+        derived["l2_hit_rate"] = g("TCC_HIT_sum") / (g("TCC_HIT_sum") + g("TCC_MISS_sum"))
+    if g("TCP_TOTAL_CACHE_ACCESSES_sum"):
+        derived["l1_hit_rate"] = 1.0 - g("TCP_TCC_READ_REQ_sum") / g("TCP_TOTAL_CACHE_ACCESSES_sum")
+    if bench:
+        rays = bench["config"]["rays_per_frame"]
+        derived["rays_per_launch"] = rays
+        derived["kernel_ms_hip_events"] = bench["roofline"]["kernel_ms"]
+        for k in ("SQ_INSTS_VMEM_RD", "SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_INSTS_SMEM"):
+            if g(k):
+                derived[k + "_per_ray"] = g(k) / rays
+        derived["executed_flops_per_launch"] = bench["roofline"]["flops_per_launch"]
+        derived["bruteforce_flops_per_ray"] = bench["roofline"].get("bruteforce_flops_per_ray")
+        derived["frac_of_fp32_peak"] = bench["roofline"]["frac"]
+    out["derived_for_timed_kernel"] = derived
+    fetch_kb, write_kb = g("FETCH_SIZE"), g("WRITE_SIZE")
+    W, H = (bench["config"]["width"], bench["config"]["height"]) if bench else (1920, 1080)
     traffic = {
-        "command": "rocprofv3 --pmc FETCH_SIZE -- python3 bench.py --steps 2 --warmup 0 --no-cpu-baseline ; "
-                   "same with --pmc WRITE_SIZE (separate passes)",
-        "kernel": main[0],
+        "command": f"rocprofv3 --pmc FETCH_SIZE -- python3 bench.py --config {cfg} --steps 2 --warmup 0 --frames-in-flight 1 "
+                   "--no-cpu-baseline ; same with --pmc WRITE_SIZE (separate passes)",
+        "kernel": main,
         "FETCH_SIZE_KB_per_launch": fetch_kb,
         "WRITE_SIZE_KB_per_launch": write_kb,
-        "fetch_correction": "x2 (gfx950 FETCH_SIZE tallies 128-B requests at 64 B); immaterial next to the writes",
+        "fetch_correction": "x2 (gfx950 FETCH_SIZE tallies 128-B requests at 64 B; calibrated for wide streaming reads, "
+                            "taken as an upper bound for the 16-B-per-lane node and sphere fetches of the tree walk)",
         "hbm_bytes_per_launch": int(fetch_kb * 1024 * 2 + write_kb * 1024),
-        "algorithmic_bytes_per_launch": 1920 * 1080 * 16,
-        "note": "framebuffer float4 stores in 64-B row segments of the 4x2 wave tile; the scene (30 KB) is "
-                "read once per workgroup into LDS",
+        "algorithmic_bytes_per_launch": W * H * 16,
+        "note": "framebuffer float4 stores in 64-B row segments of the 4x2 wave tile; scenes that fit are read once per "
+                "workgroup into LDS, larger ones (c4) are walked through L1/L2 and their misses are the fetches",
     }
-    with open(os.path.join(dst, "hbm_traffic.json"), "w") as f:
+    with open(os.path.join(dst, "hbm_traffic.json" if cfg == "c2" else f"{cfg}_hbm_traffic.json"), "w") as f:
         json.dump(traffic, f, indent=1)
-    print(json.dumps(traffic, indent=1))
-print(json.dumps(out, indent=1))
+with open(os.path.join(dst, f"{cfg}_pmc_per_launch.json"), "w") as f:
+    json.dump(out, f, indent=1)
+print(json.dumps(out.get("derived_for_timed_kernel"), indent=1))
