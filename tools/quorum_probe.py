@@ -1,26 +1,20 @@
-"""Sweep of the leaf quorum (RT_TUNE_QUORUM): how many lanes must stand on a leaf before a wave
-stops walking inner nodes and tests leaves.  64 = wait for every lane."""
-import os, sys
-import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
-import torch
+"""Frame time of the headline configuration walked by the time-sliced kernel with a slice too long to
+matter, by leaf quorum (rt_render_params.leaf_quorum): how early a wave turns to its leaves."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
 from raytrace_amd import api, scene as S
-def bench(label, ctx, W, H, spp, values):
-    buf = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
-    ref = None
-    for q in values:
-        os.environ["RT_TUNE_QUORUM"] = str(q)
-        ms = []
-        for _ in range(2):
-            ctx.render(api.Context.params(W, H, spp, 50, 1), buf.data_ptr()); st = ctx.stats(); ms.append(st["kernel_ms"])
-        img = buf.cpu().numpy()
-        if ref is None: ref = img
-        print(f"{label} quorum {q:3d}: {min(ms):8.2f} ms  {st['rays'] / min(ms) / 1e3:9.1f} Mrays/s  same image: {np.array_equal(img, ref)}", flush=True)
-aspect = float(np.float32(16 / 9))
-c = api.Context(0)
-vals = [0, 1, 2, 4, 8, 16, 32, 64]
-c.upload_scene(S.flatten(S.rtiow_scene())); c.set_camera(**S.rtiow_camera(aspect).desc())
-bench("C2", c, 1920, 1080, 50, vals)
-c.upload_scene(S.stress_flat(1000000), accel=api.RT_ACCEL_BVH); c.set_camera(**S.stress_camera(aspect).desc())
-bench("C4", c, 3840, 2160, 8, vals)
+ctx = api.Context(0)
+ctx.upload_scene(S.flatten(S.rtiow_scene()), accel=api.RT_ACCEL_BVH)
+ctx.set_camera(**S.rtiow_camera(float(np.float32(16 / 9))).desc())
+buf = torch.zeros((1080, 1920, 4), device="cuda")
+for sl, q in [(0, 0)] + [(100000, q) for q in (-1, 1, 2, 3, 4, 6, 8, 16, 64)] + [(16, 2), (32, 2), (64, 2), (32, 4), (64, 4)]:
+    best = None
+    for _ in range(3):
+        ctx.render(api.Context.params(1920, 1080, 100, 50, 1, traversal_slice=sl, leaf_quorum=q), buf.data_ptr())
+        st = ctx.stats()
+        best = st["kernel_ms"] if best is None else min(best, st["kernel_ms"])
+    ctx.render(api.Context.params(1920, 1080, 100, 50, 1, traversal_slice=sl, leaf_quorum=q, flags=api.RT_FLAG_COUNTERS), buf.data_ptr())
+    c = ctx.stats()
+    print(f"slice {sl:6d} quorum {q:3d}: {best:7.3f} ms  box tests/ray {c['box_tests'] / c['rays']:.2f}  "
+          f"traversal lane util {c['phase_clocks'][0] / (64.0 * c['phase_clocks'][1]):.3f}", flush=True)
