@@ -59,12 +59,9 @@ enum { RT_BG_SKY = 0, RT_BG_SOLID = 1 };
 /* closest-hit strategy: the reference's linear scan (sceneobject_list.h:26-39) or a BVH
  * (cuda/bvh.h); both return the same hit */
 enum { RT_ACCEL_AUTO = 0, RT_ACCEL_LIST = 1, RT_ACCEL_BVH = 2,
-       RT_ACCEL_BVH_DEVICE = 3, /* BVH built on the GPU from Morton order (where cuda/bvh.h:55-89 builds on
+       RT_ACCEL_BVH_DEVICE = 3 /* BVH built on the GPU from Morton order (where cuda/bvh.h:55-89 builds on
                                   the device too): milliseconds instead of a host build, a somewhat
-                                  slower tree; for scenes that are rebuilt often */
-       RT_ACCEL_BVH4 = 4,        /* the host-built tree with four children per node (three binary nodes
-                                  folded into one): half as many dependent node fetches per ray */
-       RT_ACCEL_BVH4_DEVICE = 5  /* the same folding applied to the GPU-built tree */ };
+                                  slower tree; for scenes that are rebuilt often */ };
 
 typedef struct rt_scene_desc {
     uint32_t struct_size;        /* sizeof(rt_scene_desc) */
@@ -159,7 +156,7 @@ typedef struct rt_stats {
     uint64_t phase_clocks[5];    /* RT_FLAG_PHASE_CLOCKS: camera, always-tested, traversal, record, scatter */
     float kernel_ms;             /* device time of the last render kernel (HIP events on its stream) */
     int32_t lanes_per_pixel;     /* value the last render used */
-    int32_t accel;               /* RT_ACCEL_LIST, RT_ACCEL_BVH or RT_ACCEL_BVH4 actually used (either builder) */
+    int32_t accel;               /* RT_ACCEL_LIST or RT_ACCEL_BVH actually used (either builder) */
     int32_t bvh_nodes, bvh_depth;
     float build_ms;              /* wall time rt_upload_scene spent building the BVH and ordering the spheres */
 } rt_stats;

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "librt_amd.so")
 RT_OK = 0
 RT_ERR_INVALID, RT_ERR_NO_DEVICE, RT_ERR_HIP, RT_ERR_NO_SCENE, RT_ERR_NO_CAMERA, RT_ERR_UNSUPPORTED = \
     -1, -2, -3, -4, -5, -6
-RT_ACCEL_AUTO, RT_ACCEL_LIST, RT_ACCEL_BVH, RT_ACCEL_BVH_DEVICE, RT_ACCEL_BVH4, RT_ACCEL_BVH4_DEVICE = 0, 1, 2, 3, 4, 5
+RT_ACCEL_AUTO, RT_ACCEL_LIST, RT_ACCEL_BVH, RT_ACCEL_BVH_DEVICE = 0, 1, 2, 3
 TRACE_NOALLOC_MAX_RAYS = 65536           # RT_TRACE_NOALLOC_MAX_RAYS
 RT_FLAG_MEAN, RT_FLAG_NO_REFINE, RT_FLAG_COUNTERS, RT_FLAG_PHASE_CLOCKS, RT_FLAG_NO_LDS_SCENE, RT_FLAG_FIXED_SUMS = 1, 2, 4, 8, 32, 64
 

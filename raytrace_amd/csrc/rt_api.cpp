@@ -299,7 +299,7 @@ int rt_upload_scene(rt_context* ctx, const rt_scene_desc* d) {
         return fail(ctx, RT_ERR_INVALID, "material arrays missing");
     if (d->n_tex > 0 && (!d->tex_type || !d->tex_color || !d->tex_a || !d->tex_b || !d->tex_off))
         return fail(ctx, RT_ERR_INVALID, "texture arrays missing");
-    if (d->accel < RT_ACCEL_AUTO || d->accel > RT_ACCEL_BVH4_DEVICE) return fail(ctx, RT_ERR_INVALID, "unknown accel");
+    if (d->accel < RT_ACCEL_AUTO || d->accel > RT_ACCEL_BVH_DEVICE) return fail(ctx, RT_ERR_INVALID, "unknown accel");
     if (d->background != RT_BG_SKY && d->background != RT_BG_SOLID) return fail(ctx, RT_ERR_INVALID, "unknown background");
     // leaf codes hold first << kLeafBits | count - 1 in 31 bits, Origin codes an index in 28
     static_assert((1LL << 28) <= (0x7fffffffLL >> rt::kLeafBits) + 1, "a leaf code holds any sphere index");
@@ -434,17 +434,15 @@ int rt_upload_scene(rt_context* ctx, const rt_scene_desc* d) {
     }
     const int64_t ns = (int64_t)sc_r.size();
 
-    bool use_bvh = d->accel >= RT_ACCEL_BVH || (d->accel == RT_ACCEL_AUTO && ns > 32);
-    const bool want_wide = d->accel == RT_ACCEL_BVH4 || d->accel == RT_ACCEL_BVH4_DEVICE;
+    bool use_bvh = d->accel == RT_ACCEL_BVH || d->accel == RT_ACCEL_BVH_DEVICE || (d->accel == RT_ACCEL_AUTO && ns > 32);
     // the GPU builder needs an inner root; a handful of spheres goes through the host builder
     // RT_ACCEL_AUTO: from 65536 spheres on the host build (0.5 s per million) costs more than the
     // few percent of traversal time its tree saves on a frame
-    bool device_build = ((d->accel == RT_ACCEL_BVH_DEVICE || d->accel == RT_ACCEL_BVH4_DEVICE) && ns > 4) || (d->accel == RT_ACCEL_AUTO && ns >= 65536);
+    bool device_build = (d->accel == RT_ACCEL_BVH_DEVICE && ns > 4) || (d->accel == RT_ACCEL_AUTO && ns >= 65536);
     const auto t_build = std::chrono::steady_clock::now();
     DeviceGuard g(ctx->device);
     rt::DScene s{};
-    int n_nodes = 0, root = rt::kNoBvh, depth = 0, stack_need = 0;
-    bool wide4 = false;
+    int n_nodes = 0, root = rt::kNoBvh, depth = 0;
     for (;;) {
         rt::BvhResult bvh;
         std::vector<int32_t> order((size_t)ns);
@@ -473,17 +471,8 @@ int rt_upload_scene(rt_context* ctx, const rt_scene_desc* d) {
         free_scene(ctx);
         s = rt::DScene{};
         int rc;
-        // the host-built tree, binary or folded into four-wide nodes (kept binary when the wide
-        // walk's worst-case stack would not fit)
-        rt::Bvh4Result w4;
-        wide4 = false;
-        if (want_wide && use_bvh && !device_build) {
-            w4 = rt::collapse_bvh4(bvh.nodes.data(), bvh.nodes.size() / 16, bvh.root);
-            wide4 = w4.root >= 0 && w4.root != rt::kNoBvh && w4.stack_need <= rt::kMaxStack - 2;
-        }
-        const std::vector<float>& host_nodes = wide4 ? w4.nodes : bvh.nodes;
-        std::vector<float4> nodes4(host_nodes.size() / 4);
-        if (!nodes4.empty()) std::memcpy(nodes4.data(), host_nodes.data(), host_nodes.size() * sizeof(float));
+        std::vector<float4> nodes4(bvh.nodes.size() / 4);
+        if (!nodes4.empty()) std::memcpy(nodes4.data(), bvh.nodes.data(), bvh.nodes.size() * sizeof(float));
         std::vector<uint8_t> texels;
         if (d->texel_bytes && d->texels) texels.assign(d->texels, d->texels + d->texel_bytes);
         if ((rc = upload(ctx, sph, &s.sph)) || (rc = upload(ctx, sph64, &s.sph64)) || (rc = upload(ctx, info, &s.sph_info)) ||
@@ -495,9 +484,7 @@ int rt_upload_scene(rt_context* ctx, const rt_scene_desc* d) {
             ctx->error = keep;
             return rc;
         }
-        n_nodes = (int)(host_nodes.size() / (wide4 ? 32 : 16)); root = use_bvh ? (wide4 ? w4.root : bvh.root) : rt::kNoBvh;
-        depth = wide4 ? w4.depth : bvh.depth;
-        stack_need = wide4 ? w4.stack_need : bvh.depth;
+        n_nodes = (int)(bvh.nodes.size() / 16); root = use_bvh ? bvh.root : rt::kNoBvh; depth = bvh.depth;
         if (device_build) {
             // build over the uploaded (input order) spheres, then permute the arrays into leaf
             // order; the second set of arrays starts as a copy so that it carries the padding
@@ -527,22 +514,7 @@ int rt_upload_scene(rt_context* ctx, const rt_scene_desc* d) {
             }
             s.sph = sph2; s.sph64 = sph642; s.sph_info = info2; s.sph_xform = xf2;   // the input-order copies stay in scene_allocs until the next upload
             s.nodes = lb.nodes;
-            n_nodes = lb.n_nodes; root = lb.root; depth = lb.depth; stack_need = lb.depth;
-            if (want_wide) {
-                // fold the GPU-built tree on the host: nodes down, four-wide nodes up
-                std::vector<float> n2((size_t)lb.n_nodes * 16);
-                RT_HIP(ctx, hipMemcpy(n2.data(), lb.nodes, n2.size() * sizeof(float), hipMemcpyDeviceToHost));
-                rt::Bvh4Result w = rt::collapse_bvh4(n2.data(), (size_t)lb.n_nodes, lb.root);
-                if (w.root >= 0 && w.root != rt::kNoBvh && w.stack_need <= rt::kMaxStack - 2) {
-                    std::vector<float4> up(w.nodes.size() / 4);
-                    std::memcpy(up.data(), w.nodes.data(), w.nodes.size() * sizeof(float));
-                    const float4* dev = nullptr;
-                    if ((rc = upload(ctx, up, &dev))) { std::string keep = ctx->error; free_scene(ctx); ctx->error = keep; return rc; }
-                    s.nodes = dev;                       // the binary nodes stay in scene_allocs until the next upload
-                    wide4 = true;
-                    n_nodes = (int)(w.nodes.size() / 32); root = w.root; depth = w.depth; stack_need = w.stack_need;
-                }
-            }
+            n_nodes = lb.n_nodes; root = lb.root; depth = lb.depth;
         }
         break;
     }
@@ -553,8 +525,6 @@ int rt_upload_scene(rt_context* ctx, const rt_scene_desc* d) {
     s.root = root;
     s.bvh_depth = depth;
     s.use_bvh = use_bvh ? 1 : 0;
-    s.bvh4 = wide4 ? 1 : 0;
-    s.stack_need = stack_need > 0 ? stack_need : 1;
     s.ids_fit_16 = (d->n_prims < 65536 && d->n_mats < 65536) ? 1 : 0;
     s.has_textures = 0;
     for (const rt::DMaterial& m : mats) if (m.tex >= 0) s.has_textures = 1;
@@ -563,7 +533,7 @@ int rt_upload_scene(rt_context* ctx, const rt_scene_desc* d) {
     s.background = d->background;
     for (int a = 0; a < 3; a++) s.bg[a] = d->bg_color[a];
     ctx->scene = s;
-    ctx->accel_used = use_bvh ? (wide4 ? RT_ACCEL_BVH4 : RT_ACCEL_BVH) : RT_ACCEL_LIST;
+    ctx->accel_used = use_bvh ? RT_ACCEL_BVH : RT_ACCEL_LIST;
     ctx->bvh_nodes = n_nodes;
     ctx->bvh_depth = depth;
     ctx->has_scene = true;

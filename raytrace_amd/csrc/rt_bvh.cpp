@@ -209,79 +209,4 @@ BvhResult build_bvh(const double* centers, const double* radii, int64_t n, int m
     return res;
 }
 
-namespace {
-
-struct Collapser {
-    const float* nodes2;
-    std::vector<float> out;
-    int depth = 0, stack_need = 0;
-
-    struct Child { int32_t ref; Box box; };
-
-    void children_of(int32_t node2, Child& l, Child& r) const {
-        const float* q = nodes2 + 16 * (size_t)node2;
-        for (int a = 0; a < 3; a++) { l.box.lo[a] = q[a]; l.box.hi[a] = q[3 + a]; r.box.lo[a] = q[6 + a]; r.box.hi[a] = q[9 + a]; }
-        std::memcpy(&l.ref, q + 12, 4);
-        std::memcpy(&r.ref, q + 13, 4);
-    }
-
-    // emits the wide node that stands for binary node `node2`; returns its index.
-    // `need`: stack entries of the worst traversal below and including this node.
-    int32_t emit(int32_t node2, int level, int* need) {
-        Child c[4];
-        int n = 2;
-        children_of(node2, c[0], c[1]);
-        while (n < 4) {
-            int pick = -1;
-            float area = -1.0f;
-            for (int i = 0; i < n; i++)
-                if (c[i].ref >= 0 && c[i].box.half_area() > area) { area = c[i].box.half_area(); pick = i; }
-            if (pick < 0) break;
-            Child l, r;
-            children_of(c[pick].ref, l, r);
-            c[pick] = l;
-            c[n++] = r;
-        }
-        const int32_t me = (int32_t)(out.size() / 32);
-        out.resize(out.size() + 32);
-        depth = std::max(depth, level + 1);
-        int below = 0;
-        int32_t refs[4];
-        for (int i = 0; i < 4; i++) {
-            if (i < n) {
-                int sub = 0;
-                refs[i] = c[i].ref >= 0 ? emit(c[i].ref, level + 1, &sub) : c[i].ref;
-                below = std::max(below, sub);
-            } else {
-                refs[i] = (int32_t)0x80000000;                 // never met: the slot's box is empty
-                c[i].box.reset();
-            }
-        }
-        float* q = out.data() + 32 * (size_t)me;               // (out may have grown: take the address now)
-        for (int a = 0; a < 3; a++)
-            for (int i = 0; i < 4; i++) { q[8 * a + i] = c[i].box.lo[a]; q[8 * a + 4 + i] = c[i].box.hi[a]; }
-        std::memcpy(q + 24, refs, 16);
-        for (int i = 28; i < 32; i++) q[i] = 0.0f;
-        *need = (n - 1) + below;
-        return me;
-    }
-};
-
-}  // namespace
-
-Bvh4Result collapse_bvh4(const float* nodes2, size_t n_nodes2, int32_t root2) {
-    Bvh4Result res;
-    res.root = root2;
-    if (root2 < 0 || root2 == 0x7fffffff || n_nodes2 == 0) return res;      // a leaf or nothing: no inner node to widen
-    Collapser c;
-    c.nodes2 = nodes2;
-    c.out.reserve(n_nodes2 * 16);
-    int need = 0;
-    res.root = c.emit(root2, 0, &need);
-    res.depth = c.depth;
-    res.stack_need = need;
-    res.nodes = std::move(c.out);
-    return res;
-}
-
 }  // namespace rt

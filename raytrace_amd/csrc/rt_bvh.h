@@ -25,21 +25,4 @@ struct BvhResult {
 // node visit in units of one sphere test).
 BvhResult build_bvh(const double* centers, const double* radii, int64_t n, int max_depth, int leaf_max = 4, float node_cost = 0.0f);
 
-// Four-wide form of a binary tree (either builder's): every inner node takes the place of up to
-// three binary nodes and holds up to four children, which halves the number of dependent node
-// fetches of a traversal.  A node is 32 floats:
-//   x lo[4], x hi[4], y lo[4], y hi[4], z lo[4], z hi[4], child codes[4] (int bits), unused[4]
-// Child codes are wide-node indices (>= 0) or the binary tree's leaf codes (< 0); an empty slot
-// has the box (+inf, -inf), which no ray meets.
-struct Bvh4Result {
-    std::vector<float> nodes;
-    int32_t root = 0x7fffffff;    // wide index, leaf code, or kNoBvh
-    int32_t depth = 0;            // wide inner levels on the longest root-to-leaf path
-    int32_t stack_need = 0;       // most entries a traversal stack can hold at once: the sum of (children - 1) down the worst path
-};
-
-// nodes2: the binary tree's 16-float nodes; root2: its root code.  Greedy by surface area: the
-// largest inner child is opened until the node has four children or only leaves.
-Bvh4Result collapse_bvh4(const float* nodes2, size_t n_nodes2, int32_t root2);
-
 }  // namespace rt

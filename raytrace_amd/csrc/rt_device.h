@@ -68,8 +68,6 @@ struct DScene {
     int n_nodes;
     int root;             // inner index, leaf code, or kNoBvh
     int bvh_depth;
-    int bvh4;             // nodes are the four-wide 128-byte nodes of rt_bvh.h (8 float4 each), else the binary ones
-    int stack_need;       // most entries a traversal stack holds at once
     int use_bvh;          // 0: scan all ordinary spheres in order
     int ids_fit_16;       // every list position and material index is below 65536
     int has_textures;     // some material reads a texture

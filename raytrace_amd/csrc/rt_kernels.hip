@@ -225,47 +225,38 @@ __device__ __forceinline__ SlabRay slab_ray(V3 o, V3 dh) {
 
 // Where the traversal reads its geometry from: HBM (through L1/L2), or a copy in LDS that the
 // workgroup makes at kernel start when the whole BVH and sphere list fit.
-template <bool WIDE>
-struct GeoGlobalT {
+struct GeoGlobal {
     static constexpr bool kPrefetchLeaf = true;
     static constexpr bool kPlaneAddressed = false;
-    static constexpr bool kWide = WIDE;
     const float4* nodes; const float4* sph; const int2* info;
     __device__ __forceinline__ int root_ref(int root) const { return root; }
-    __device__ __forceinline__ float4 node(int i, int q) const { return nodes[(WIDE ? 8 : 4) * (size_t)i + q]; }
+    __device__ __forceinline__ float4 node(int i, int q) const { return nodes[4 * (size_t)i + q]; }
     __device__ __forceinline__ float4 sphere(int i) const { return sph[i]; }
     __device__ __forceinline__ int obj(int i) const { return info[i].x; }
     __device__ __forceinline__ int mat(int i) const { return info[i].y; }
 };
-using GeoGlobal = GeoGlobalT<false>;
-// The LDS copy of the nodes is laid out for the slab test.  Binary nodes, 64 bytes:
+// The LDS copy of the nodes is laid out for the slab test: 64 bytes per node,
 //   [x: left lo, left hi, right lo, right hi][y: the same][z: the same][left ref, right ref, -, -]
-// four-wide nodes, 112 bytes:
-//   [x: lo0 hi0 lo1 hi1 lo2 hi2 lo3 hi3][y: the same][z: the same][ref0 ref1 ref2 ref3]
 // so that the plane a ray enters a child's slab through sits at (axis base + 4 bytes if the
 // direction component is negative) and the plane it leaves through at that address with bit 2
-// flipped.  A lane reads the six planes per child it needs through addresses that carry
+// flipped.  A lane reads the six planes of both children it needs through addresses that carry
 // its ray's signs, instead of reading all twelve and selecting; the selects were a fifth of the
 // node step's VALU time and LDS has bandwidth to spare.  Inner-node references are the nodes' LDS
-// byte addresses (node_base + index * node size), leaves keep their negative codes.
+// byte addresses (node_base + index * 64), leaves keep their negative codes.
 typedef const float __attribute__((address_space(3))) lds_cfloat;
 typedef const int __attribute__((address_space(3))) lds_cint;
 typedef int __attribute__((address_space(3))) lds_int;
-template <bool WIDE>
-struct GeoLdsT {
+struct GeoLds {
     static constexpr bool kPrefetchLeaf = false;
     static constexpr bool kPlaneAddressed = true;
-    static constexpr bool kWide = WIDE;
-    static constexpr int kNodeBytes = WIDE ? 112 : 64;
     unsigned node_base;                                          // LDS byte address of node 0
     const float4* sph; const int* objs;                          // both point into LDS
-    __device__ __forceinline__ int root_ref(int root) const { return root >= 0 ? (int)node_base + root * kNodeBytes : root; }   // a tiny scene's root is a leaf
+    __device__ __forceinline__ int root_ref(int root) const { return root >= 0 ? (int)node_base + (root << 6) : root; }   // a tiny scene's root is a leaf
     __device__ __forceinline__ float4 sphere(int i) const { return sph[i]; }
     // list position and material share a word (both below 65536 in a scene that fits in LDS)
     __device__ __forceinline__ int obj(int i) const { return objs[i] & 0xffff; }
     __device__ __forceinline__ int mat(int i) const { return (int)((unsigned)objs[i] >> 16); }
 };
-using GeoLds = GeoLdsT<false>;
 
 template <bool COUNT, class G>
 __device__ __forceinline__ void leaf_sphere(const G& geo, int i, float4 s, V3 o, V3 dh, float tn_min, int self, Cand& best, Counters& cn) {
@@ -435,61 +426,6 @@ __device__ __forceinline__ void hit_own_sphere(const G& geo, V3 o, const RayN& r
     }
 }
 
-constexpr int kTravDone = (int)0x80000000;     // not a leaf code: ~kTravDone >> kLeafBits = 2^28 - 1 with count 8, and a leaf
-                                               // holds at most four spheres of at most 2^28 (rt_upload_scene's limit)
-
-// One step of the four-wide walk: the four child boxes of node `cur` against the ray, the children
-// that are met sorted by entry distance (five compare-exchanges on (distance, reference) pairs,
-// a child that is not met counting as infinitely far), the nearest taken next and the others
-// pushed farthest first.  Returns the next node, leaf code, or kTravDone.
-__device__ __forceinline__ void order2(float& ta, int& ra, float& tb, int& rb) {
-    const bool swap = tb < ta;
-    const float t = swap ? tb : ta; tb = swap ? ta : tb; ta = t;
-    const int r = swap ? rb : ra; rb = swap ? ra : rb; ra = r;
-}
-template <bool COUNT, class G>
-__device__ __forceinline__ int wide_step(const G& geo, int cur, const SlabRay& sr, unsigned enter_x, unsigned enter_y, unsigned enter_z,
-                                         float tn_min, float tn_max, unsigned& top, unsigned bottom, Counters& cn) {
-    constexpr unsigned kStackStride = kBlock * sizeof(int);
-    float t0, t1, t2, t3;
-    int r0, r1, r2, r3;
-    bool h0, h1, h2, h3;
-    if (COUNT) cn.box += 4;
-    if constexpr (G::kPlaneAddressed) {
-        const unsigned ax = (unsigned)cur + enter_x, ay = (unsigned)cur + enter_y, az = (unsigned)cur + enter_z;
-        lds_cfloat* ex = (lds_cfloat*)(size_t)ax; lds_cfloat* lx = (lds_cfloat*)(size_t)(ax ^ 4u);
-        lds_cfloat* ey = (lds_cfloat*)(size_t)ay; lds_cfloat* ly = (lds_cfloat*)(size_t)(ay ^ 4u);
-        lds_cfloat* ez = (lds_cfloat*)(size_t)az; lds_cfloat* lz = (lds_cfloat*)(size_t)(az ^ 4u);
-        lds_cint* refs = (lds_cint*)(size_t)((unsigned)cur + 96u);
-        r0 = refs[0]; r1 = refs[1]; r2 = refs[2]; r3 = refs[3];
-        h0 = box_planes(ex[0], ey[0], ez[0], lx[0], ly[0], lz[0], sr.idir, sr.oid, sr.slack, tn_min, tn_max, t0);
-        h1 = box_planes(ex[2], ey[2], ez[2], lx[2], ly[2], lz[2], sr.idir, sr.oid, sr.slack, tn_min, tn_max, t1);
-        h2 = box_planes(ex[4], ey[4], ez[4], lx[4], ly[4], lz[4], sr.idir, sr.oid, sr.slack, tn_min, tn_max, t2);
-        h3 = box_planes(ex[6], ey[6], ez[6], lx[6], ly[6], lz[6], sr.idir, sr.oid, sr.slack, tn_min, tn_max, t3);
-    } else {
-        const float4 xl = geo.node(cur, 0), xh = geo.node(cur, 1), yl = geo.node(cur, 2), yh = geo.node(cur, 3),
-                     zl = geo.node(cur, 4), zh = geo.node(cur, 5), rf = geo.node(cur, 6);
-        r0 = __float_as_int(rf.x); r1 = __float_as_int(rf.y); r2 = __float_as_int(rf.z); r3 = __float_as_int(rf.w);
-        h0 = box_test(xl.x, yl.x, zl.x, xh.x, yh.x, zh.x, sr.idir, sr.oid, sr.neg, sr.slack, tn_min, tn_max, t0);
-        h1 = box_test(xl.y, yl.y, zl.y, xh.y, yh.y, zh.y, sr.idir, sr.oid, sr.neg, sr.slack, tn_min, tn_max, t1);
-        h2 = box_test(xl.z, yl.z, zl.z, xh.z, yh.z, zh.z, sr.idir, sr.oid, sr.neg, sr.slack, tn_min, tn_max, t2);
-        h3 = box_test(xl.w, yl.w, zl.w, xh.w, yh.w, zh.w, sr.idir, sr.oid, sr.neg, sr.slack, tn_min, tn_max, t3);
-    }
-    t0 = h0 ? t0 : kInf; t1 = h1 ? t1 : kInf; t2 = h2 ? t2 : kInf; t3 = h3 ? t3 : kInf;
-    order2(t0, r0, t1, r1); order2(t2, r2, t3, r3);
-    order2(t0, r0, t2, r2); order2(t1, r1, t3, r3);
-    order2(t1, r1, t2, r2);
-    if (t3 < kInf) { *(lds_int*)(size_t)top = r3; top += kStackStride; }
-    if (t2 < kInf) { *(lds_int*)(size_t)top = r2; top += kStackStride; }
-    if (t1 < kInf) { *(lds_int*)(size_t)top = r1; top += kStackStride; }
-    if (t0 < kInf) return r0;
-    if (top != bottom) {
-        top -= kStackStride;
-        return *(lds_int*)(size_t)top;
-    }
-    return kTravDone;
-}
-
 // BVH traversal, near child first, as two nested loops: the inner one walks inner nodes until
 // every lane of the wave stands on a leaf (or has finished), then all those lanes test their
 // leaves together.  A leaf costs as much as two node steps and only one lane step in eight is
@@ -501,6 +437,8 @@ __device__ __forceinline__ int wide_step(const G& geo, int cur, const SlabRay& s
 // wave leaves after about that many node steps; lanes whose traversal is not finished
 // (cur != kTravDone) come back later with the same state, so one long ray does not hold the
 // other 63 lanes of the wave.
+constexpr int kTravDone = (int)0x80000000;     // not a leaf code: ~kTravDone >> kLeafBits = 2^28 - 1 with count 8, and a leaf
+                                               // holds at most four spheres of at most 2^28 (rt_upload_scene's limit)
 
 template <bool COUNT, bool SLICED, class G>
 __device__ __forceinline__ void hit_bvh(const G& geo, V3 o, const RayN& rn, Origin from, int* stack, int budget, int quorum,
@@ -511,10 +449,9 @@ __device__ __forceinline__ void hit_bvh(const G& geo, V3 o, const RayN& rn, Orig
     const SlabRay sr = slab_ray(o, dh);
     unsigned enter_x = 0u, enter_y = 0u, enter_z = 0u;    // plane-addressed nodes: where this ray's entry planes sit in a node
     if constexpr (G::kPlaneAddressed) {
-        constexpr unsigned kAxis = G::kWide ? 32u : 16u;      // bytes of planes per axis
         enter_x = sr.neg.x ? 4u : 0u;
-        enter_y = kAxis + (sr.neg.y ? 4u : 0u);
-        enter_z = 2u * kAxis + (sr.neg.z ? 4u : 0u);
+        enter_y = sr.neg.y ? 20u : 16u;
+        enter_z = sr.neg.z ? 36u : 32u;
     }
     // the stack top as an LDS byte address: a push or pop is one add and one LDS access
     constexpr unsigned kStackStride = kBlock * sizeof(int);
@@ -533,9 +470,6 @@ __device__ __forceinline__ void hit_bvh(const G& geo, V3 o, const RayN& rn, Orig
         bool leave = false;
         while (cur >= 0 && !stop && !leave) {
             if (COUNT) { cn.steps++; if (first_active_lane()) cn.wave_steps++; }
-            if constexpr (G::kWide) {
-                cur = wide_step<COUNT>(geo, cur, sr, enter_x, enter_y, enter_z, tn_min, best.tn, top, bottom, cn);
-            } else {
             int left, right;
             float tl, tr;
             bool hl, hr;
@@ -570,7 +504,6 @@ __device__ __forceinline__ void hit_bvh(const G& geo, V3 o, const RayN& rn, Orig
             } else {
                 cur = kTravDone;
             }
-            }
             if constexpr (SLICED) {
                 waiting += __popcll(__ballot(cur < 0 && cur != kTravDone));
                 leave = waiting * quorum >= __popcll(__ballot(cur >= 0));
@@ -604,16 +537,11 @@ __device__ __forceinline__ Cand closest_hit(const DScene& sc, V3 o, V3 d, float 
     Cand best = no_hit();
     RayN rn = normalise(d, t_min);
     hit_always<COUNT, true>(sc, o, d, rn, t_min, no_origin(), best, cn);
+    GeoGlobal geo = {sc.nodes, sc.sph, sc.sph_info};
     if (!sc.use_bvh) hit_list<COUNT, false>(sc, nullptr, o, rn, no_origin(), best, cn);
     else if (sc.root != kNoBvh) {
         int cur = sc.root, sp = 0;
-        if (sc.bvh4) {
-            GeoGlobalT<true> geo = {sc.nodes, sc.sph, sc.sph_info};
-            hit_bvh<COUNT, false>(geo, o, rn, no_origin(), stack, 0, 0, cur, sp, best, cn);
-        } else {
-            GeoGlobal geo = {sc.nodes, sc.sph, sc.sph_info};
-            hit_bvh<COUNT, false>(geo, o, rn, no_origin(), stack, 0, 0, cur, sp, best, cn);
-        }
+        hit_bvh<COUNT, false>(geo, o, rn, no_origin(), stack, 0, 0, cur, sp, best, cn);
     }
     return best;
 }
@@ -961,51 +889,34 @@ __device__ __forceinline__ bool shade(const DScene& sc, const G& geo, const DRen
     return !cont || depth >= rp.max_depth;             // main.cc:13-14: the limit ends in black
 }
 
-template <bool LDS, bool WIDE>
-struct GeoOf { using type = GeoGlobalT<WIDE>; };
-template <bool WIDE>
-struct GeoOf<true, WIDE> { using type = GeoLdsT<WIDE>; };
+template <bool LDS>
+struct GeoOf { using type = GeoGlobal; };
+template <>
+struct GeoOf<true> { using type = GeoLds; };
 
 // Copies the BVH and the sphere list into LDS (LDS variant) behind `lds`.
-template <bool LDS, bool WIDE>
-__device__ __forceinline__ typename GeoOf<LDS, WIDE>::type stage_geometry(const DScene& sc, int* lds) {
+template <bool LDS>
+__device__ __forceinline__ typename GeoOf<LDS>::type stage_geometry(const DScene& sc, int* lds) {
     if constexpr (LDS) {
-        constexpr int kNodeBytes = GeoLdsT<WIDE>::kNodeBytes;
         float4* nodes = reinterpret_cast<float4*>(lds);
-        float4* sph = nodes + (kNodeBytes / 16) * sc.n_nodes;
+        float4* sph = nodes + 4 * sc.n_nodes;
         int* objs = reinterpret_cast<int*>(sph + sc.n_sph_padded);
         const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)nodes;
         for (int i = threadIdx.x; i < sc.n_nodes; i += kBlock) {
-            if constexpr (WIDE) {
-                // device layout: x lo[4], x hi[4], y lo[4], y hi[4], z lo[4], z hi[4], refs[4], -
-                float4* n = nodes + 7 * i;
-#pragma unroll
-                for (int a = 0; a < 3; a++) {
-                    const float4 lo = sc.nodes[8 * i + 2 * a], hi = sc.nodes[8 * i + 2 * a + 1];
-                    n[2 * a] = make_float4(lo.x, hi.x, lo.y, hi.y);
-                    n[2 * a + 1] = make_float4(lo.z, hi.z, lo.w, hi.w);
-                }
-                const float4 rf = sc.nodes[8 * i + 6];
-                int r[4] = {__float_as_int(rf.x), __float_as_int(rf.y), __float_as_int(rf.z), __float_as_int(rf.w)};
-#pragma unroll
-                for (int k = 0; k < 4; k++) r[k] = r[k] >= 0 ? (int)base + r[k] * kNodeBytes : r[k];
-                n[6] = make_float4(__int_as_float(r[0]), __int_as_float(r[1]), __int_as_float(r[2]), __int_as_float(r[3]));
-            } else {
-                // device layout: left box lo xyz, hi xyz, right box lo xyz, hi xyz, left, right
-                const float4 q0 = sc.nodes[4 * i], q1 = sc.nodes[4 * i + 1], q2 = sc.nodes[4 * i + 2], q3 = sc.nodes[4 * i + 3];
-                const int l = __float_as_int(q3.x), r = __float_as_int(q3.y);
-                nodes[4 * i + 0] = make_float4(q0.x, q0.w, q1.z, q2.y);
-                nodes[4 * i + 1] = make_float4(q0.y, q1.x, q1.w, q2.z);
-                nodes[4 * i + 2] = make_float4(q0.z, q1.y, q2.x, q2.w);
-                nodes[4 * i + 3] = make_float4(__int_as_float(l >= 0 ? (int)base + (l << 6) : l), __int_as_float(r >= 0 ? (int)base + (r << 6) : r), 0.0f, 0.0f);
-            }
+            // device layout: left box lo xyz, hi xyz, right box lo xyz, hi xyz, left, right
+            const float4 q0 = sc.nodes[4 * i], q1 = sc.nodes[4 * i + 1], q2 = sc.nodes[4 * i + 2], q3 = sc.nodes[4 * i + 3];
+            const int l = __float_as_int(q3.x), r = __float_as_int(q3.y);
+            nodes[4 * i + 0] = make_float4(q0.x, q0.w, q1.z, q2.y);
+            nodes[4 * i + 1] = make_float4(q0.y, q1.x, q1.w, q2.z);
+            nodes[4 * i + 2] = make_float4(q0.z, q1.y, q2.x, q2.w);
+            nodes[4 * i + 3] = make_float4(__int_as_float(l >= 0 ? (int)base + (l << 6) : l), __int_as_float(r >= 0 ? (int)base + (r << 6) : r), 0.0f, 0.0f);
         }
         for (int i = threadIdx.x; i < sc.n_sph; i += kBlock) { sph[i] = sc.sph[i]; int2 f = sc.sph_info[i]; objs[i] = f.x | (f.y << 16); }
         for (int i = sc.n_sph + threadIdx.x; i < sc.n_sph_padded; i += kBlock) { sph[i] = sc.sph[i]; objs[i] = 0; }   // the scan's padding
-        GeoLdsT<WIDE> g = {base, sph, objs};
+        GeoLds g = {base, sph, objs};
         return g;
     } else {
-        GeoGlobalT<WIDE> g = {sc.nodes, sc.sph, sc.sph_info};
+        GeoGlobal g = {sc.nodes, sc.sph, sc.sph_info};
         return g;
     }
 }
@@ -1034,7 +945,7 @@ __device__ __forceinline__ float from_fixed(unsigned long long q) { return (floa
 // MODE: 0 linear scan, 1 BVH, 2 BVH walked in time slices.  Each combination is a kernel of its
 // own: code that a scene never runs (rects, the scan, the tree walk) still costs the code that
 // does run registers and scheduling freedom when it shares a kernel with it.
-template <bool COUNT, bool LDS, bool PROF, int MODE, bool RECTS, bool WIDE>
+template <bool COUNT, bool LDS, bool PROF, int MODE, bool RECTS>
 __global__ __launch_bounds__(kBlock, MODE == 0 ? RT_WG_PER_CU_SCAN : RT_WG_PER_CU) void render_kernel(DScene sc, DCamera cam, DRender rp, float4* __restrict__ out,
                                                         unsigned long long* __restrict__ counters) {
     constexpr bool SLICED = MODE == 2, BVH = MODE != 0;
@@ -1050,7 +961,7 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? RT_WG_PER_CU_SCAN : RT_WG_PER_C
     // pixel table: (x, j) of the q-th pixel of the two tiles, x = -1 where a tile hangs over the image
     int2* tile_pix = reinterpret_cast<int2*>(accum + 6 * P);
     int* tile_row = reinterpret_cast<int*>(accum + 8 * P);   // first framebuffer row of the two tiles
-    const auto geo = stage_geometry<LDS, WIDE>(sc, s_dyn + rp.stack_depth * kBlock + (kBlock / 64) * accum_words * 2);
+    const auto geo = stage_geometry<LDS>(sc, s_dyn + rp.stack_depth * kBlock + (kBlock / 64) * accum_words * 2);
     const float4* staged_list = geo.sph;               // the scan reads it when LDS (else it takes the records through scalar loads)
     (void)staged_list;
     __syncthreads();
@@ -1322,9 +1233,9 @@ hipError_t launch_render(const DScene& sc, const DCamera& cam, const DRender& rp
     // when it all fits in a budget that still leaves four workgroups per CU, a copy of the BVH
     // and the sphere list
     DRender r = rp;
-    r.stack_depth = sc.use_bvh ? sc.stack_need + 1 : 1;  // binary tree: one push per inner level at most; four-wide: up to three
+    r.stack_depth = sc.use_bvh ? sc.bvh_depth + 1 : 1;   // one push per inner level at most
     size_t lds = (size_t)r.stack_depth * kBlock * sizeof(int) + (size_t)(kBlock / 64) * (8 * (64 / rp.lanes_per_pixel) + 1) * sizeof(unsigned long long);
-    const size_t geo_bytes = (size_t)sc.n_nodes * (sc.bvh4 ? 112 : 64) + (size_t)sc.n_sph_padded * 20;
+    const size_t geo_bytes = (size_t)sc.n_nodes * 64 + (size_t)sc.n_sph_padded * 20;
     // the tree walk keeps tree and spheres in LDS up to 40 KB per workgroup.  The scan reads a
     // short list (a room with a few balls) from LDS: 6 % faster than through scalar loads, whose
     // latency a loop of one or two trips cannot hide; a long list is faster through scalar loads
@@ -1346,8 +1257,7 @@ hipError_t launch_render(const DScene& sc, const DCamera& cam, const DRender& rp
 
     const bool sliced = sc.use_bvh && r.slice > 0;
 #define RT_LAUNCH(...) hipLaunchKernelGGL((render_kernel<__VA_ARGS__>), grid, block, lds, stream, sc, cam, r, out, counters)
-#define RT_LAUNCH_W(C, L, P, M, R) do { if (M != 0 && sc.bvh4) RT_LAUNCH(C, L, P, M, R, (M != 0)); else RT_LAUNCH(C, L, P, M, R, false); } while (0)
-#define RT_LAUNCH_R(C, L, P, M) do { if (sc.n_rects > 0 || sc.has_textures) RT_LAUNCH_W(C, L, P, M, true); else RT_LAUNCH_W(C, L, P, M, false); } while (0)
+#define RT_LAUNCH_R(C, L, P, M) do { if (sc.n_rects > 0 || sc.has_textures) RT_LAUNCH(C, L, P, M, true); else RT_LAUNCH(C, L, P, M, false); } while (0)
 #define RT_LAUNCH_M(C, P) do { \
         if (!sc.use_bvh) { if (in_lds) RT_LAUNCH_R(C, true, P, 0); else RT_LAUNCH_R(C, false, P, 0); } \
         else if (in_lds) { if (sliced) RT_LAUNCH_R(C, true, P, 2); else RT_LAUNCH_R(C, true, P, 1); } \
@@ -1358,7 +1268,6 @@ hipError_t launch_render(const DScene& sc, const DCamera& cam, const DRender& rp
     else RT_LAUNCH_M(false, false);
 #undef RT_LAUNCH_M
 #undef RT_LAUNCH_R
-#undef RT_LAUNCH_W
 #undef RT_LAUNCH
     return hipGetLastError();
 }
