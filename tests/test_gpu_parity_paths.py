@@ -58,6 +58,50 @@ def test_depth_limit_two_pins_every_pixel(api, S, rtiow_flat, oracle, reference,
     ctx.close()
 
 
+# ---- primary hit ids through the frame kernels themselves ---------------------------------------------------
+
+def test_primary_hit_ids_through_every_frame_kernel(api, S, oracle):
+    """rt_trace_primary walks the tree in HBM in one go; a frame is rendered by other instances of
+    the walk (nodes in LDS read through sign-carrying addresses, time slices, either builder's tree,
+    the scan).  Here every sphere of the reference's scene emits a colour that spells its list
+    position, the depth limit is 1 and there is one sample per pixel, so a pixel of the frame IS the
+    id of its camera ray's closest hit: each kernel's frame is decoded and compared with the
+    checker's, pixel by pixel (the camera ray included: jitter and lens draws of camera.h:40-45)."""
+    rec = S.rtiow_records()
+    w = S.sceneobject_list()
+    for k, o in enumerate(rec):
+        w.add(S.sphere(o[0:3], o[3], S.diffuse_light(((k & 31) / 32 + 1 / 64, ((k >> 5) & 31) / 32 + 1 / 64, 1.0))))
+    flat = S.flatten(w, background=S.RT_BG_SOLID, bg_color=(0, 0, 0))
+    W, H, seed = 240, 160, 12
+    cam = dict(lookfrom=(6, 3, -13), lookat=(0, 0, 0), vup=(0, 1, 0), vfov=20.0, aspect=1.5, aperture=0.1, focus_dist=10.0)
+
+    def decode(img):
+        hit = img[..., 2] > 0.5
+        ids = np.floor(img[..., 0] * 32).astype(np.int64) + 32 * np.floor(img[..., 1] * 32).astype(np.int64)
+        return np.where(hit, ids, -1)
+
+    sums, rays = oracle.render(flat, oracle.camera(**cam), W, H, 1, 1, seed, threads=8)
+    want = decode(sums)
+    assert rays == W * H and len(np.unique(want)) > 100 and (want == 0).mean() > 0.3        # the ground is id 0
+    P = api.Context.params
+    frames = []
+    for accel, kw in ((api.RT_ACCEL_BVH, {}), (api.RT_ACCEL_BVH, dict(flags=api.RT_FLAG_NO_LDS_SCENE)),
+                      (api.RT_ACCEL_BVH, dict(traversal_slice=3)), (api.RT_ACCEL_BVH, dict(traversal_slice=5, leaf_quorum=1, flags=api.RT_FLAG_NO_LDS_SCENE)),
+                      (api.RT_ACCEL_BVH_DEVICE, {}), (api.RT_ACCEL_BVH_DEVICE, dict(traversal_slice=2, leaf_quorum=-1)), (api.RT_ACCEL_LIST, {})):
+        ctx = api.Context(0)
+        ctx.upload_scene(flat, accel=accel)
+        ctx.set_camera(**cam)
+        img = ctx.render_host(P(W, H, 1, 1, seed, **kw))
+        assert ctx.stats()["rays"] == W * H
+        got = decode(img)
+        # a camera ray that grazes a silhouette closer than single precision resolves may fall on either side
+        assert (got != want).sum() <= 4, (accel, kw, int((got != want).sum()))
+        frames.append(img)
+        ctx.close()
+    for f in frames[1:]:
+        assert np.array_equal(f, frames[0])
+
+
 # ---- camera path (cuda/main.cu:220-279) against the checker ---------------------------------------------
 
 @pytest.mark.parametrize("frame", [150, 450])
