@@ -131,7 +131,7 @@ static inline void S(get_ray)(const S(cam)* c, R s, R t, S(rng)* g, S(v3)* ro, S
 void S(rto_get_ray)(const double* cam, double s, double t, uint64_t seed, uint32_t pixel,
                     uint32_t sample, uint32_t first_draw, double* ray, uint32_t* draws_used) {
     S(cam) c = S(cam_load)(cam);
-    S(rng) g = { seed, pixel, sample, {{0}, {0}, 0, 0} };
+    S(rng) g = { seed, pixel, sample, {{0}, {0}, 0, 0, 0} };
     S(rng_seg)(&g, 0, first_draw);
     S(v3) o, d;
     S(get_ray)(&c, (R)s, (R)t, &g, &o, &d);
@@ -141,7 +141,7 @@ void S(rto_get_ray)(const double* cam, double s, double t, uint64_t seed, uint32
 
 void S(rto_sample)(int which, uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t segment,
                    double* out, uint32_t* draws_used) {
-    S(rng) g = { seed, pixel, sample, {{0}, {0}, 0, 0} };
+    S(rng) g = { seed, pixel, sample, {{0}, {0}, 0, 0, 0} };
     S(rng_seg)(&g, segment, 0);
     S(v3) v = which == 0 ? S(in_unit_sphere)(&g) : which == 1 ? S(unit_vector_rnd)(&g)
                                                               : S(in_unit_disk)(&g);
@@ -395,7 +395,7 @@ int S(rto_scatter)(const rto_scene* sc, int mat, const double* ray_in, const dou
     h.normal = S(mk)((R)nrm[0], (R)nrm[1], (R)nrm[2]);
     h.front = front;
     if (uv) { h.u = (R)uv[0]; h.v = (R)uv[1]; }
-    S(rng) g = { seed, pixel, sample, {{0}, {0}, 0, 0} };
+    S(rng) g = { seed, pixel, sample, {{0}, {0}, 0, 0, 0} };
     S(rng_seg)(&g, segment, 0);
     S(v3) att, so, sd, em;
     int ok = S(scatter)(sc, mat, S(mk)((R)ray_in[3], (R)ray_in[4], (R)ray_in[5]), &h, &g,
@@ -451,7 +451,7 @@ static S(v3) S(ray_color)(const rto_scene* sc, S(v3) o, S(v3) d, int depth, R t_
 void S(rto_ray_color)(const rto_scene* sc, const double* ray, int depth, double t_min,
                       uint64_t seed, uint32_t pixel, uint32_t sample, double* rgb,
                       uint64_t* rays) {
-    S(rng) g = { seed, pixel, sample, {{0}, {0}, 0, 0} };
+    S(rng) g = { seed, pixel, sample, {{0}, {0}, 0, 0, 0} };
     uint64_t nr = 0;
     S(v3) c = S(ray_color)(sc, S(mk)((R)ray[0], (R)ray[1], (R)ray[2]),
                            S(mk)((R)ray[3], (R)ray[4], (R)ray[5]), depth, (R)t_min, &g, &nr);
@@ -476,7 +476,7 @@ uint64_t S(rto_render)(const rto_scene* sc, const double* camd, int W, int H, in
             S(v3) acc = S(mk)(0, 0, 0);
             uint32_t pix = (uint32_t)(j * W + i);
             for (int s = sample_begin; s < sample_begin + spp; s++) {
-                S(rng) g = { seed, pix, (uint32_t)s, {{0}, {0}, 0, 0} };
+                S(rng) g = { seed, pix, (uint32_t)s, {{0}, {0}, 0, 0, 0} };
                 S(rng_seg)(&g, 0, 0);
                 R u = ((R)i + S(rnd)(&g)) / (R)(W - 1);
                 R v = ((R)j + S(rnd)(&g)) / (R)(H - 1);

@@ -725,27 +725,35 @@ struct Key { uint32_t seed_lo, seed_hi, pixel, sample; };
 __device__ __forceinline__ float u01(uint32_t w) { return (float)(w >> 8) * 5.9604644775390625e-08f; }  // 2^-24
 __device__ __forceinline__ float pm1(uint32_t w) { return fmaf(2.0f, u01(w), -1.0f); }                   // random_double(-1,1)
 
-// xoshiro128++ (Blackman, Vigna): the draws of a segment beyond its Philox block.
+// The draws of a segment beyond its Philox block: one step of the xoshiro128 linear engine
+// (Blackman, Vigna) per rejection ATTEMPT, started from the block as state and stepped twice before
+// the first such attempt (every state word then carries w.w, which no direct draw of a scatter
+// segment uses).  An attempt's draws are s0 + s3, s1 + s2 and, for a sphere triple, s0 - s3 of the new
+// state: bits 8..31, the ones a uniform uses, are exactly uniform and independent for a uniform
+// state (disjoint words; s0 - s3 = (s0 + s3) - 2 s3 shares only bit 0 with s0 + s3), and the sum is
+// xoshiro128+'s scrambler, weak only in its lowest bits.  A wave iterates a rejection loop until its
+// unluckiest lane is done (five more trips for thirty lanes), so the loop body is what counts: ten
+// integer operations per attempt instead of thirty for three calls of xoshiro128++.
 struct Xo { uint32_t s0, s1, s2, s3; };
 __device__ __forceinline__ uint32_t rotl32(uint32_t x, int k) { return __builtin_rotateleft32(x, k); }
-__device__ __forceinline__ uint32_t xo_next(Xo& g) {
-    uint32_t result = rotl32(g.s0 + g.s3, 7) + g.s0;
+__device__ __forceinline__ void xo_step(Xo& g) {
     uint32_t t = g.s1 << 9;
     g.s2 ^= g.s0; g.s3 ^= g.s1; g.s1 ^= g.s2; g.s0 ^= g.s3;
     g.s2 ^= t;
     g.s3 = rotl32(g.s3, 11);
-    return result;
 }
 
 // vec3.h:130-136.  The first rejection attempt of a scatter segment reads words 0,1,2 of the
 // segment's Philox block (first draw z, then y, then x: the argument evaluation order of the
-// reference build, vec3.h:60); later attempts step xoshiro128++ from the block.
+// reference build, vec3.h:60); later attempts come from the stepped engine, in the same order.
 __device__ __forceinline__ V3 in_unit_sphere(uint4 w) {
     V3 p = mk(pm1(w.z), pm1(w.y), pm1(w.x));
     if (dot(p, p) >= 1.0f) {
         Xo g; g.s0 = w.x; g.s1 = w.y; g.s2 = w.z; g.s3 = w.w;
+        xo_step(g);
         for (int i = 0; i < 256; i++) {
-            float z = pm1(xo_next(g)), y = pm1(xo_next(g)), x = pm1(xo_next(g));
+            xo_step(g);
+            float z = pm1(g.s0 + g.s3), y = pm1(g.s1 + g.s2), x = pm1(g.s0 - g.s3);
             p = mk(x, y, z);
             if (!(dot(p, p) >= 1.0f)) break;
         }
@@ -813,7 +821,7 @@ __device__ __forceinline__ bool scatter(const DScene& sc, const DMaterial& m, V3
 
 // Segment 0 of a sample: its Philox block holds the two pixel jitters (words 0,1) and the first
 // lens-disk attempt (word 2 -> y, word 3 -> x: vec3.h:152 evaluated right to left); further
-// attempts step xoshiro128++ from the block.
+// attempts come from the stepped xoshiro128 engine (see Xo).
 __device__ __forceinline__ void camera_ray(const DCamera& cam, const DRender& rp, const Key& k, int i, int j, V3& o, V3& d) {
     uint4 w = philox4x32_10(k.pixel, k.sample, 0u, 0u, k.seed_lo, k.seed_hi);
     float s = ((float)i + u01(w.x)) * rp.inv_wm1;
@@ -823,8 +831,10 @@ __device__ __forceinline__ void camera_ray(const DCamera& cam, const DRender& rp
         float py = pm1(w.z), px = pm1(w.w);
         if (fmaf(px, px, py * py) >= 1.0f) {
             Xo g; g.s0 = w.x; g.s1 = w.y; g.s2 = w.z; g.s3 = w.w;
+            xo_step(g);
             for (int a = 0; a < 256; a++) {
-                py = pm1(xo_next(g)); px = pm1(xo_next(g));
+                xo_step(g);
+                py = pm1(g.s0 + g.s3); px = pm1(g.s1 + g.s2);
                 if (!(fmaf(px, px, py * py) >= 1.0f)) break;
             }
         }

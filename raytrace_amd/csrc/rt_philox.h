@@ -4,7 +4,7 @@
 //     counter = (pixel, sample, segment, 0)   key = (seed_lo, seed_hi)
 // where segment 0 holds a sample's camera draws and segment k >= 1 the scatter draws after the
 // k-th closest-hit query.  The block's words are the segment's first draws; a rejection loop
-// that needs more steps xoshiro128++ from the block (rt_kernels.hip).  Uniforms are
+// that needs more steps the xoshiro128 engine from the block, once per attempt (rt_kernels.hip).  Uniforms are
 // (word >> 8) * 2^-24, in [0,1) like random_double().
 #pragma once
 
