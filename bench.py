@@ -194,6 +194,8 @@ def main():
     ap.add_argument("--frames-in-flight", type=int, choices=[1, 2], default=2,
                     help="2: frame k+1 is launched on a second stream before frame k is collected; "
                          "1: one frame at a time (what the kernel-trace profile is taken with)")
+    ap.add_argument("--float-nodes", action="store_true",
+                    help="walk a tree that lives in HBM through its 64-byte float nodes, not the 32-byte quantised ones (A/B)")
     ap.add_argument("--check", action="store_true",
                     help="rank 0 also renders every timed frame alone and compares it bit for bit with the assembled one")
     args = ap.parse_args()
@@ -275,7 +277,10 @@ def main():
 
     tiles = (TILE_ROWS, rank, world) if world > 1 else (0, 0, 0)
     max_rows = rdist.max_shard_rows(H, TILE_ROWS, world) if (world > 1 and partition == "tiles") else H
-    P = api.Context.params
+    extra_flags = api.RT_FLAG_FLOAT_NODES if args.float_nodes else 0
+
+    def P(*a, flags=0, **kw):
+        return api.Context.params(*a, flags=flags | extra_flags, **kw)
     fbufs = [torch.zeros((max_rows, W, 4), dtype=torch.float32, device="cuda") for _ in range(n_buf)]
     ibufs = [torch.zeros((H, W, 4), dtype=torch.int64, device="cuda") for _ in range(n_buf)] if (world > 1 and partition != "tiles") else None
     rgb8 = [torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda") for _ in range(n_buf)] if wl.path else None
@@ -498,7 +503,7 @@ def main():
                        "accel": args.accel, "tile_rows": TILE_ROWS if (world > 1 and partition == "tiles") else None,
                        "partition": how,
                        "rays_per_frame": rays_total / args.steps, "lanes_per_pixel": st["lanes_per_pixel"],
-                       "bvh_depth": st["bvh_depth"], "bvh_nodes": st["bvh_nodes"], "bvh_build_ms": build_ms,
+                       "bvh_depth": st["bvh_depth"], "bvh_nodes": st["bvh_nodes"], "bvh_coarse_nodes": st["bvh_coarse_nodes"], "bvh_build_ms": build_ms,
                        "frames_in_flight": args.frames_in_flight if args.steps > 1 else 1},
             "roofline": {"bound": "valu", "achieved": flops / (kernel_ms * 1e-3) / 1e12,
                          "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",

@@ -109,6 +109,8 @@ enum {
     RT_FLAG_COUNTERS = 1u << 2,   /* also count box/sphere/rect tests (slower; for the roofline) */
     RT_FLAG_PHASE_CLOCKS = 1u << 3, /* diagnostic build: wave clocks per phase into rt_stats.phase_clocks */
     RT_FLAG_NO_LDS_SCENE = 1u << 5, /* read BVH and spheres from HBM even when they would fit in LDS */
+    RT_FLAG_FLOAT_NODES = 1u << 7, /* a tree read from HBM is walked through its 64-byte single-precision nodes
+                                     instead of the 32-byte quantised ones (same image; for comparison) */
     RT_FLAG_FIXED_SUMS = 1u << 6  /* the image is written as the kernel accumulates it: per pixel four uint64_t
                                      (r, g, b sums of sample radiance in unsigned 32.32 fixed point, sample
                                      count), 32 bytes.  Integer sums of sample windows (sample_begin) add up
@@ -159,6 +161,9 @@ typedef struct rt_stats {
     int32_t accel;               /* RT_ACCEL_LIST or RT_ACCEL_BVH actually used (either builder) */
     int32_t bvh_nodes, bvh_depth;
     float build_ms;              /* wall time rt_upload_scene spent building the BVH and ordering the spheres */
+    int32_t bvh_coarse_nodes;    /* inner nodes whose boxes the 16-bit grid of the 32-byte nodes would blow up to more than
+                                    twice their surface area; 0: a walk out of HBM reads the 32-byte nodes, else the
+                                    64-byte ones */
 } rt_stats;
 
 int rt_create(int device, rt_context** out);

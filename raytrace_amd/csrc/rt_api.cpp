@@ -31,6 +31,7 @@ struct rt_context {
     int accel_used = RT_ACCEL_LIST;
     int bvh_nodes = 0, bvh_depth = 0;
     float build_ms = 0.0f;
+    int coarse_nodes = 0;          // nodes the 16-bit grid is too coarse for (any: the tree is walked in its float form)
 
     // per-render state
     unsigned long long* counters = nullptr;   // device, rt::kNumCounters
@@ -518,6 +519,31 @@ int rt_upload_scene(rt_context* ctx, const rt_scene_desc* d) {
         }
         break;
     }
+    ctx->coarse_nodes = 0;
+    if (use_bvh && n_nodes > 0 && root >= 0 && root != rt::kNoBvh) {
+        // 32-byte nodes for walks out of HBM: planes on a 16-bit grid over the root's box
+        float rn[16];
+        RT_HIP(ctx, hipMemcpy(rn, s.nodes + 4 * (size_t)root, sizeof(rn), hipMemcpyDeviceToHost));
+        float lo[3], step[3];
+        for (int a = 0; a < 3; a++) {
+            const float l = std::fmin(rn[a], rn[6 + a]), h = std::fmax(rn[3 + a], rn[9 + a]);
+            lo[a] = l;
+            step[a] = (float)(((double)h - (double)l) * (1.0 + 1e-6) / 65535.0);
+            if (!(step[a] > 0.0f) || !std::isfinite(step[a])) step[a] = 1e-30f;
+            s.q_lo[a] = lo[a]; s.q_step[a] = step[a];
+        }
+        void* qn = nullptr;
+        RT_HIP(ctx, hipMalloc(&qn, (size_t)n_nodes * 32));
+        ctx->scene_allocs.push_back(qn);
+        RT_HIP(ctx, rt::quantize_nodes(s.nodes, n_nodes, lo, step, static_cast<uint4*>(qn), &ctx->coarse_nodes, ctx->stream));
+        // a grid too coarse for some node (fine detail in a wide scene): the tree keeps its float form
+        if (ctx->coarse_nodes == 0) {
+            s.qnodes = static_cast<const uint4*>(qn);
+        } else {
+            ctx->scene_allocs.pop_back();
+            (void)hipFree(qn);
+        }
+    }
     ctx->build_ms = use_bvh ? std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_build).count() : 0.0f;
     s.n_sph = (int)ns;
     s.n_sph_padded = (int)((ns + 3) / 4 * 4);      // what the linear scan walks; the arrays hold four records more
@@ -670,6 +696,7 @@ int rt_get_stats(rt_context* ctx, rt_stats* out) {
     out->bvh_nodes = ctx->bvh_nodes;
     out->bvh_depth = ctx->bvh_depth;
     out->build_ms = ctx->build_ms;
+    out->bvh_coarse_nodes = ctx->coarse_nodes;
     return RT_OK;
 }
 

@@ -65,6 +65,8 @@ struct DScene {
     int n_sph_padded;     // n_sph rounded up to a multiple of 4: the linear scan's extent (the padding cannot be hit);
                           // the arrays hold four more records, for leaves that are read four at a time
     const float4* nodes;
+    const uint4* qnodes;  // the same nodes in 32 bytes (16-bit planes on the grid q_lo + k * q_step), or null when the grid is too coarse for some node: what frames walk out of HBM
+    float q_lo[3], q_step[3];
     int n_nodes;
     int root;             // inner index, leaf code, or kNoBvh
     int bvh_depth;

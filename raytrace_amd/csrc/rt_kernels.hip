@@ -228,9 +228,25 @@ __device__ __forceinline__ SlabRay slab_ray(V3 o, V3 dh) {
 struct GeoGlobal {
     static constexpr bool kPrefetchLeaf = true;
     static constexpr bool kPlaneAddressed = false;
+    static constexpr bool kQuant = false;
     const float4* nodes; const float4* sph; const int2* info;
     __device__ __forceinline__ int root_ref(int root) const { return root; }
     __device__ __forceinline__ float4 node(int i, int q) const { return nodes[4 * (size_t)i + q]; }
+    __device__ __forceinline__ float4 sphere(int i) const { return sph[i]; }
+    __device__ __forceinline__ int obj(int i) const { return info[i].x; }
+    __device__ __forceinline__ int mat(int i) const { return info[i].y; }
+};
+// The tree in HBM as 32-byte nodes (rt_lbvh.h, quantize_nodes): two 16-byte loads per node instead of
+// four.  The walk of a large scene is bound by the L1's tag lookups (the lanes of a wave stand at
+// different nodes, so every 16-byte load is a lookup per lane), not by bytes or arithmetic.
+struct GeoGlobalQ {
+    static constexpr bool kPrefetchLeaf = true;
+    static constexpr bool kPlaneAddressed = false;
+    static constexpr bool kQuant = true;
+    const uint4* qnodes; const float4* sph; const int2* info;
+    float lo[3], step[3];
+    __device__ __forceinline__ int root_ref(int root) const { return root; }
+    __device__ __forceinline__ uint4 qnode(int i, int q) const { return qnodes[2 * (size_t)i + q]; }
     __device__ __forceinline__ float4 sphere(int i) const { return sph[i]; }
     __device__ __forceinline__ int obj(int i) const { return info[i].x; }
     __device__ __forceinline__ int mat(int i) const { return info[i].y; }
@@ -249,6 +265,7 @@ typedef int __attribute__((address_space(3))) lds_int;
 struct GeoLds {
     static constexpr bool kPrefetchLeaf = false;
     static constexpr bool kPlaneAddressed = true;
+    static constexpr bool kQuant = false;
     unsigned node_base;                                          // LDS byte address of node 0
     const float4* sph; const int* objs;                          // both point into LDS
     __device__ __forceinline__ int root_ref(int root) const { return root >= 0 ? (int)node_base + (root << 6) : root; }   // a tiny scene's root is a leaf
@@ -453,6 +470,25 @@ __device__ __forceinline__ void hit_bvh(const G& geo, V3 o, const RayN& rn, Orig
         enter_y = sr.neg.y ? 20u : 16u;
         enter_z = sr.neg.z ? 36u : 32u;
     }
+    // quantised nodes: a plane is lo + k * step, so its distance along the ray is k * (step / d) +
+    // (lo - o) / d: grid origin and step are folded into the ray's constants, and the plane a ray
+    // enters through is the low or the high half of a dword by the sign of its direction
+    V3 qa = mk(0.0f, 0.0f, 0.0f), qb = mk(0.0f, 0.0f, 0.0f);
+    unsigned sh_x = 0u, sh_y = 0u, sh_z = 0u;
+    float slack_q = 0.0f;
+    if constexpr (G::kQuant) {
+        qa = mk(geo.step[0] * sr.idir.x, geo.step[1] * sr.idir.y, geo.step[2] * sr.idir.z);
+        qb = mk(fmaf(geo.lo[0], sr.idir.x, sr.oid.x), fmaf(geo.lo[1], sr.idir.y, sr.oid.y), fmaf(geo.lo[2], sr.idir.z, sr.oid.z));
+        sh_x = sr.neg.x ? 16u : 0u; sh_y = sr.neg.y ? 16u : 0u; sh_z = sr.neg.z ? 16u : 0u;
+        // rounding error bound of k * qa + qb, from the sizes of the terms that were added up
+        // (an axis the ray does not move along has a reciprocal of 1e30 and decides by sign alone)
+        const float lim = 1.0e30f;
+        const float mx = fabsf(sr.idir.x) < lim ? fabsf(sr.oid.x) + fabsf(geo.lo[0] * sr.idir.x) + 65536.0f * fabsf(qa.x) : 0.0f;
+        const float my = fabsf(sr.idir.y) < lim ? fabsf(sr.oid.y) + fabsf(geo.lo[1] * sr.idir.y) + 65536.0f * fabsf(qa.y) : 0.0f;
+        const float mz = fabsf(sr.idir.z) < lim ? fabsf(sr.oid.z) + fabsf(geo.lo[2] * sr.idir.z) + 65536.0f * fabsf(qa.z) : 0.0f;
+        const float big = fmaxf(fmaxf(mx, my), mz);
+        slack_q = isfinite(big) ? 8.0e-7f * big : 0.0f;
+    }
     // the stack top as an LDS byte address: a push or pop is one add and one LDS access
     constexpr unsigned kStackStride = kBlock * sizeof(int);
     const unsigned bottom = (unsigned)(size_t)(__attribute__((address_space(3))) char*)stack;
@@ -483,6 +519,17 @@ __device__ __forceinline__ void hit_bvh(const G& geo, V3 o, const RayN& rn, Orig
                 left = refs[0]; right = refs[1];
                 hl = box_planes(ex[0], ey[0], ez[0], lx[0], ly[0], lz[0], sr.idir, sr.oid, sr.slack, tn_min, best.tn, tl);
                 hr = box_planes(ex[2], ey[2], ez[2], lx[2], ly[2], lz[2], sr.idir, sr.oid, sr.slack, tn_min, best.tn, tr);
+            } else if constexpr (G::kQuant) {
+                const uint4 a = geo.qnode(cur, 0), b = geo.qnode(cur, 1);
+                left = (int)b.z; right = (int)b.w;
+#define RT_QPLANE(word, shift) ((float)__builtin_amdgcn_ubfe((word), (shift), 16u))
+                hl = box_planes(RT_QPLANE(a.x, sh_x), RT_QPLANE(a.y, sh_y), RT_QPLANE(a.z, sh_z),
+                                RT_QPLANE(a.x, sh_x ^ 16u), RT_QPLANE(a.y, sh_y ^ 16u), RT_QPLANE(a.z, sh_z ^ 16u),
+                                qa, qb, slack_q, tn_min, best.tn, tl);
+                hr = box_planes(RT_QPLANE(a.w, sh_x), RT_QPLANE(b.x, sh_y), RT_QPLANE(b.y, sh_z),
+                                RT_QPLANE(a.w, sh_x ^ 16u), RT_QPLANE(b.x, sh_y ^ 16u), RT_QPLANE(b.y, sh_z ^ 16u),
+                                qa, qb, slack_q, tn_min, best.tn, tr);
+#undef RT_QPLANE
             } else {
                 float4 q0 = geo.node(cur, 0), q1 = geo.node(cur, 1), q2 = geo.node(cur, 2), q3 = geo.node(cur, 3);
                 left = __float_as_int(q3.x); right = __float_as_int(q3.y);
@@ -899,14 +946,16 @@ __device__ __forceinline__ bool shade(const DScene& sc, const G& geo, const DRen
     return !cont || depth >= rp.max_depth;             // main.cc:13-14: the limit ends in black
 }
 
-template <bool LDS>
+template <bool LDS, bool QUANT>
 struct GeoOf { using type = GeoGlobal; };
 template <>
-struct GeoOf<true> { using type = GeoLds; };
+struct GeoOf<false, true> { using type = GeoGlobalQ; };
+template <bool QUANT>
+struct GeoOf<true, QUANT> { using type = GeoLds; };
 
 // Copies the BVH and the sphere list into LDS (LDS variant) behind `lds`.
-template <bool LDS>
-__device__ __forceinline__ typename GeoOf<LDS>::type stage_geometry(const DScene& sc, int* lds) {
+template <bool LDS, bool QUANT>
+__device__ __forceinline__ typename GeoOf<LDS, QUANT>::type stage_geometry(const DScene& sc, int* lds) {
     if constexpr (LDS) {
         float4* nodes = reinterpret_cast<float4*>(lds);
         float4* sph = nodes + 4 * sc.n_nodes;
@@ -924,6 +973,9 @@ __device__ __forceinline__ typename GeoOf<LDS>::type stage_geometry(const DScene
         for (int i = threadIdx.x; i < sc.n_sph; i += kBlock) { sph[i] = sc.sph[i]; int2 f = sc.sph_info[i]; objs[i] = f.x | (f.y << 16); }
         for (int i = sc.n_sph + threadIdx.x; i < sc.n_sph_padded; i += kBlock) { sph[i] = sc.sph[i]; objs[i] = 0; }   // the scan's padding
         GeoLds g = {base, sph, objs};
+        return g;
+    } else if constexpr (QUANT) {
+        GeoGlobalQ g = {sc.qnodes, sc.sph, sc.sph_info, {sc.q_lo[0], sc.q_lo[1], sc.q_lo[2]}, {sc.q_step[0], sc.q_step[1], sc.q_step[2]}};
         return g;
     } else {
         GeoGlobal g = {sc.nodes, sc.sph, sc.sph_info};
@@ -955,7 +1007,7 @@ __device__ __forceinline__ float from_fixed(unsigned long long q) { return (floa
 // MODE: 0 linear scan, 1 BVH, 2 BVH walked in time slices.  Each combination is a kernel of its
 // own: code that a scene never runs (rects, the scan, the tree walk) still costs the code that
 // does run registers and scheduling freedom when it shares a kernel with it.
-template <bool COUNT, bool LDS, bool PROF, int MODE, bool RECTS>
+template <bool COUNT, bool LDS, bool PROF, int MODE, bool RECTS, bool QUANT>
 __global__ __launch_bounds__(kBlock, MODE == 0 ? RT_WG_PER_CU_SCAN : RT_WG_PER_CU) void render_kernel(DScene sc, DCamera cam, DRender rp, float4* __restrict__ out,
                                                         unsigned long long* __restrict__ counters) {
     constexpr bool SLICED = MODE == 2, BVH = MODE != 0;
@@ -971,7 +1023,7 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? RT_WG_PER_CU_SCAN : RT_WG_PER_C
     // pixel table: (x, j) of the q-th pixel of the two tiles, x = -1 where a tile hangs over the image
     int2* tile_pix = reinterpret_cast<int2*>(accum + 6 * P);
     int* tile_row = reinterpret_cast<int*>(accum + 8 * P);   // first framebuffer row of the two tiles
-    const auto geo = stage_geometry<LDS>(sc, s_dyn + rp.stack_depth * kBlock + (kBlock / 64) * accum_words * 2);
+    const auto geo = stage_geometry<LDS, QUANT>(sc, s_dyn + rp.stack_depth * kBlock + (kBlock / 64) * accum_words * 2);
     const float4* staged_list = geo.sph;               // the scan reads it when LDS (else it takes the records through scalar loads)
     (void)staged_list;
     __syncthreads();
@@ -1267,7 +1319,10 @@ hipError_t launch_render(const DScene& sc, const DCamera& cam, const DRender& rp
 
     const bool sliced = sc.use_bvh && r.slice > 0;
 #define RT_LAUNCH(...) hipLaunchKernelGGL((render_kernel<__VA_ARGS__>), grid, block, lds, stream, sc, cam, r, out, counters)
-#define RT_LAUNCH_R(C, L, P, M) do { if (sc.n_rects > 0 || sc.has_textures) RT_LAUNCH(C, L, P, M, true); else RT_LAUNCH(C, L, P, M, false); } while (0)
+    // a tree read from HBM is walked through its 32-byte quantised nodes
+    const bool quant = sc.use_bvh && !in_lds && sc.qnodes != nullptr && (rp.flags & 128u) == 0u;
+#define RT_LAUNCH_Q(C, L, P, M, R) do { if (!L && M != 0 && quant) RT_LAUNCH(C, L, P, M, R, (!L && M != 0)); else RT_LAUNCH(C, L, P, M, R, false); } while (0)
+#define RT_LAUNCH_R(C, L, P, M) do { if (sc.n_rects > 0 || sc.has_textures) RT_LAUNCH_Q(C, L, P, M, true); else RT_LAUNCH_Q(C, L, P, M, false); } while (0)
 #define RT_LAUNCH_M(C, P) do { \
         if (!sc.use_bvh) { if (in_lds) RT_LAUNCH_R(C, true, P, 0); else RT_LAUNCH_R(C, false, P, 0); } \
         else if (in_lds) { if (sliced) RT_LAUNCH_R(C, true, P, 2); else RT_LAUNCH_R(C, true, P, 1); } \
@@ -1278,6 +1333,7 @@ hipError_t launch_render(const DScene& sc, const DCamera& cam, const DRender& rp
     else RT_LAUNCH_M(false, false);
 #undef RT_LAUNCH_M
 #undef RT_LAUNCH_R
+#undef RT_LAUNCH_Q
 #undef RT_LAUNCH
     return hipGetLastError();
 }

@@ -27,4 +27,16 @@ hipError_t gather_spheres(const int* order, int n, const float4* sph, const doub
                           const int* xform, float4* sph_out, double4* sph64_out, int2* info_out, int* xform_out,
                           hipStream_t stream);
 
+// 32-byte form of the binary nodes for trees walked out of HBM: each of the twelve box planes of a
+// node as a 16-bit step count from the low corner of the scene's box (`lo`, steps of `step` per
+// axis), the low planes rounded down and the high planes up, so a quantised box contains its box;
+// then the two child codes.  Per node two 16-byte loads instead of four.
+//   dwords 0-2: left  box x, y, z as (lo | hi << 16)    dwords 3-5: right box    dwords 6, 7: left, right
+// *n_coarse: the number of nodes for which the grid is too coarse, that is, blows the surface area
+// of either box up to more than twice its size (fine detail in a wide scene).  Such a node would be
+// visited, and descended from, that much more often: a tree that has any is better walked in its
+// float form.  Synchronises `stream`.
+hipError_t quantize_nodes(const float4* nodes, int n_nodes, const float lo[3], const float step[3], uint4* out, int* n_coarse,
+                          hipStream_t stream);
+
 }  // namespace rt

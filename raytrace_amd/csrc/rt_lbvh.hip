@@ -348,6 +348,60 @@ hipError_t build_lbvh(const double4* sph64, int n, hipStream_t stream, LbvhResul
     return hipSuccess;
 }
 
+// One thread per node.  The plane a traversal works with is lo + q * step in exact arithmetic (it
+// folds lo and step into the ray's constants and rounds once); q is chosen here, in double, so that
+// this exact plane lies on the outer side of the node's own plane.
+constexpr double kCoarseArea = 2.0;
+
+__global__ __launch_bounds__(kThreads) void quantize_kernel(const float4* __restrict__ nodes, int n, float lx, float ly, float lz,
+                                                            float sx, float sy, float sz, uint4* __restrict__ out, int* __restrict__ n_coarse) {
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n) return;
+    const float4 q0 = nodes[4 * (size_t)i], q1 = nodes[4 * (size_t)i + 1], q2 = nodes[4 * (size_t)i + 2], q3 = nodes[4 * (size_t)i + 3];
+    const float blo[2][3] = {{q0.x, q0.y, q0.z}, {q1.z, q1.w, q2.x}}, bhi[2][3] = {{q0.w, q1.x, q1.y}, {q2.y, q2.z, q2.w}};
+    const double lo[3] = {lx, ly, lz}, st[3] = {sx, sy, sz};
+    unsigned w[6];
+    bool is_coarse = false;
+    for (int c = 0; c < 2; c++) {
+        double ext[3], qext[3];
+        for (int a = 0; a < 3; a++) {
+            double ql = floor(((double)blo[c][a] - lo[a]) / st[a]), qh = ceil(((double)bhi[c][a] - lo[a]) / st[a]);
+            if (lo[a] + ql * st[a] > (double)blo[c][a]) ql -= 1.0;
+            if (lo[a] + qh * st[a] < (double)bhi[c][a]) qh += 1.0;
+            ql = ql < 0.0 ? 0.0 : (ql > 65535.0 ? 65535.0 : ql);
+            qh = qh < 0.0 ? 0.0 : (qh > 65535.0 ? 65535.0 : qh);
+            w[3 * c + a] = (unsigned)ql | ((unsigned)qh << 16);
+            ext[a] = (double)bhi[c][a] - (double)blo[c][a];
+            qext[a] = (qh - ql) * st[a];
+        }
+        const double area = ext[0] * ext[1] + ext[1] * ext[2] + ext[2] * ext[0];
+        const double qarea = qext[0] * qext[1] + qext[1] * qext[2] + qext[2] * qext[0];
+        is_coarse = is_coarse || !(qarea <= kCoarseArea * area);
+    }
+    out[2 * (size_t)i] = make_uint4(w[0], w[1], w[2], w[3]);
+    out[2 * (size_t)i + 1] = make_uint4(w[4], w[5], __float_as_uint(q3.x), __float_as_uint(q3.y));
+    if (is_coarse) atomicAdd(n_coarse, 1);
+}
+
+hipError_t quantize_nodes(const float4* nodes, int n_nodes, const float lo[3], const float step[3], uint4* out, int* n_coarse,
+                          hipStream_t stream) {
+    *n_coarse = 0;
+    if (n_nodes <= 0) return hipSuccess;
+    int* count = nullptr;
+    hipError_t e = hipMalloc(&count, sizeof(int));
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(count, 0, sizeof(int), stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(quantize_kernel, dim3(blocks(n_nodes)), dim3(kThreads), 0, stream, nodes, n_nodes, lo[0], lo[1], lo[2],
+                           step[0], step[1], step[2], out, count);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(n_coarse, count, sizeof(int), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    (void)hipFree(count);
+    return e;
+}
+
 hipError_t gather_spheres(const int* order, int n, const float4* sph, const double4* sph64, const int2* info,
                           const int* xform, float4* sph_out, double4* sph64_out, int2* info_out, int* xform_out,
                           hipStream_t stream) {

@@ -91,6 +91,8 @@ def test_primary_hit_ids_through_every_frame_kernel(api, S, oracle):
     P = api.Context.params
     frames = []
     for accel, kw in ((api.RT_ACCEL_BVH, {}), (api.RT_ACCEL_BVH, dict(flags=api.RT_FLAG_NO_LDS_SCENE)),
+                      (api.RT_ACCEL_BVH, dict(flags=api.RT_FLAG_NO_LDS_SCENE | api.RT_FLAG_FLOAT_NODES)),
+                      (api.RT_ACCEL_BVH_DEVICE, dict(traversal_slice=4, flags=api.RT_FLAG_NO_LDS_SCENE | api.RT_FLAG_FLOAT_NODES)),
                       (api.RT_ACCEL_BVH, dict(traversal_slice=3)), (api.RT_ACCEL_BVH, dict(traversal_slice=5, leaf_quorum=1, flags=api.RT_FLAG_NO_LDS_SCENE)),
                       (api.RT_ACCEL_BVH_DEVICE, {}), (api.RT_ACCEL_BVH_DEVICE, dict(traversal_slice=2, leaf_quorum=-1)), (api.RT_ACCEL_LIST, {})):
         ctx = api.Context(0)
@@ -389,3 +391,76 @@ def test_auto_accel_survives_a_scene_too_deep_for_the_gpu_builder(api, S):
         assert np.array_equal(auto[f], scan[f]), f
     assert (scan["id"] >= 0).mean() > 0.5 and (scan["id"][:63] >= 0).sum() > 40
     ctx.close()
+
+
+# ---- 32-byte quantised nodes against the 64-byte float nodes and the scan ------------------------------------------------------
+
+def mixed_scale_scene(S, offset, r_min=2e-4):
+    """40 000 emitters with radii from r_min to 30 in a box 2 000 wide, optionally far from the
+    origin, each emitting its list position; every tenth is of the smallest and sits in front of the
+    camera at a distance where they cover pixels.  Returns the scene, the camera and the ids of
+    those small ones."""
+    rng = np.random.default_rng(11)
+    n = 40000
+    c = rng.random((n, 3)) * [2000.0, 40.0, 2000.0] + offset
+    r = r_min * (30.0 / r_min) ** rng.random(n) ** 3
+    near = np.arange(0, n, 10)
+    cam_from = np.array([1000.0, 20.0, -260.0]) + offset
+    s = r_min / 2e-4
+    c[near] = cam_from + s * np.stack([rng.uniform(-0.02, 0.02, len(near)), rng.uniform(-0.012, 0.012, len(near)), rng.uniform(0.1, 0.2, len(near))], 1)
+    r[near] = rng.uniform(r_min, 3 * r_min, len(near))
+    k = np.arange(n)
+    param = np.zeros((n, 5))
+    param[:, 0] = (k % 256 + 0.5) / 256
+    param[:, 1] = (k // 256 + 0.5) / 256
+    param[:, 2] = 1.0
+    flat = S.FlatScene(prim_type=np.zeros(n, np.int32), prim_geom=np.concatenate([c, r[:, None], np.zeros((n, 2))], 1),
+                       prim_mat=np.arange(n, dtype=np.int32), mat_type=np.full(n, S.RT_DIFFUSE_LIGHT, np.int32), mat_param=param,
+                       mat_tex=-np.ones(n, np.int32), tex_type=np.zeros(0, np.int32), tex_color=np.zeros((0, 3)),
+                       tex_a=np.zeros(0, np.int32), tex_b=np.zeros(0, np.int32), tex_off=np.zeros(0, np.int64), texels=np.zeros(0, np.uint8),
+                       background=S.RT_BG_SOLID, bg_color=(0.0, 0.0, 0.0))
+    cam = dict(lookfrom=tuple(cam_from), lookat=tuple(np.array([1000.0, 20.0, 1000.0]) + offset), vup=(0, 1, 0), vfov=12.0, aspect=1.5,
+               aperture=0.0, focus_dist=10.0)
+    return flat, cam, near
+
+
+@pytest.mark.parametrize("offset,r_min", [(0.0, 0.15), (3.0e4, 0.15), (0.0, 2e-4)])
+def test_quantised_nodes_lose_no_hit_on_a_scene_of_mixed_scales(api, S, offset, r_min):
+    """A tree read from HBM is walked through nodes whose planes are 16-bit steps of the scene's box,
+    0.03 wide in this scene: a fifth of the smallest radius in the first two cases, a hundred times
+    the smallest radius in the third, where the tree must therefore keep its float form.  At depth
+    1 a pixel is the id of the closest hit: the walk through quantised nodes, the walk through
+    float nodes and the scan of the list must agree on every pixel and every ray count, for both
+    builders."""
+    flat, cam, near = mixed_scale_scene(S, offset, r_min)
+    W, H = 192, 128
+    P = api.Context.params
+    frames, rays = {}, {}
+    for name, accel, flags in (("list", api.RT_ACCEL_LIST, 0),
+                               ("host quantised", api.RT_ACCEL_BVH, api.RT_FLAG_NO_LDS_SCENE),
+                               ("host float", api.RT_ACCEL_BVH, api.RT_FLAG_NO_LDS_SCENE | api.RT_FLAG_FLOAT_NODES),
+                               ("device quantised", api.RT_ACCEL_BVH_DEVICE, api.RT_FLAG_NO_LDS_SCENE),
+                               ("device float", api.RT_ACCEL_BVH_DEVICE, api.RT_FLAG_NO_LDS_SCENE | api.RT_FLAG_FLOAT_NODES)):
+        ctx = api.Context(0)
+        ctx.upload_scene(flat, accel=accel)
+        ctx.set_camera(**cam)
+        frames[name] = ctx.render_host(P(W, H, 2, 1, 3, flags=flags | api.RT_FLAG_COUNTERS))
+        rays[name] = ctx.stats()["rays"]
+        if name == "host quantised":
+            box_q = ctx.stats()["box_tests"]
+            coarse = ctx.stats()["bvh_coarse_nodes"] / ctx.stats()["bvh_nodes"]
+        if name == "host float":
+            box_f = ctx.stats()["box_tests"]
+        ctx.close()
+    ids = np.floor(frames["list"][..., 0] / 2 * 256).astype(int) + 256 * np.floor(frames["list"][..., 1] / 2 * 256).astype(int)
+    seen = np.unique(ids[frames["list"][..., 2] > 1.5])
+    assert len(seen) > 300 and np.isin(seen, near).sum() > 20          # far and near, large and tiny spheres are in the picture
+    for name, f in frames.items():
+        assert np.array_equal(f, frames["list"]), name
+        assert rays[name] == rays["list"], name
+    if r_min > 0.1:
+        # the quantised boxes are a little larger: a few more visits, never fewer
+        assert coarse == 0 and box_f < box_q <= 1.25 * box_f, (coarse, box_f, box_q)
+    else:
+        # nodes over spheres far smaller than a step of the grid: the flag changes nothing
+        assert 0.05 < coarse < 0.5 and box_q == box_f, (coarse, box_f, box_q)
