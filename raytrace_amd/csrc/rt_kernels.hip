@@ -181,45 +181,54 @@ __device__ __forceinline__ bool rect_test(const DRect& r, float num, V3 o, V3 d,
 // two planes the ray meets first follows from the sign of its direction alone, so the near and far
 // plane are picked by that sign (a select) instead of by min/max of the two distances: min, max
 // and compare issue at half the rate of a select or a multiply-add on this hardware.  Boxes are
-// padded on the host; the exit distance is widened by a few ulps plus `slack` (the rounding error
-// bound of the fused form, proportional to |o/d|), so rounding can only add visits, never lose a
-// hit.
+// padded on the host.  The rounding error of the fused form is proportional to |o/d| of its axis:
+// it is folded into the constants, taken off for the planes a ray enters through (oid_in) and
+// added for the planes it leaves through (oid_out), so rounding can only add visits, never lose a
+// hit, and the test itself has no term for it.  The bound is per axis on purpose: |o/d| is huge on
+// an axis the ray barely moves along, and one bound for all three (the largest) would let such a
+// ray into every box along its way, whichever axes the box misses it on; rays like that are few,
+// but a wave waits for its slowest lane.
 struct SlabSigns { bool x, y, z; };                    // direction component negative
 // the test proper, from the three planes the ray enters through and the three it leaves through
 __device__ __forceinline__ bool box_planes(float enter_x, float enter_y, float enter_z, float leave_x, float leave_y, float leave_z,
-                                           V3 idir, V3 oid, float slack, float tn_min, float tn_max, float& t_enter) {
-    float nx = fmaf(enter_x, idir.x, oid.x), fx = fmaf(leave_x, idir.x, oid.x);
-    float ny = fmaf(enter_y, idir.y, oid.y), fy = fmaf(leave_y, idir.y, oid.y);
-    float nz = fmaf(enter_z, idir.z, oid.z), fz = fmaf(leave_z, idir.z, oid.z);
+                                           V3 idir, V3 oid_in, V3 oid_out, float tn_min, float tn_max, float& t_enter) {
+    float nx = fmaf(enter_x, idir.x, oid_in.x), fx = fmaf(leave_x, idir.x, oid_out.x);
+    float ny = fmaf(enter_y, idir.y, oid_in.y), fy = fmaf(leave_y, idir.y, oid_out.y);
+    float nz = fmaf(enter_z, idir.z, oid_in.z), fz = fmaf(leave_z, idir.z, oid_out.z);
     float tnear = fmaxf(fmaxf(fmaxf(nx, ny), nz), tn_min);
     float tfar = fminf(fminf(fminf(fx, fy), fz), tn_max);
     t_enter = tnear;
-    return tnear <= fmaf(tfar, 1.0000005f, slack);
+    return tnear <= tfar * 1.0000005f;
 }
 __device__ __forceinline__ bool box_test(float bx0, float by0, float bz0, float bx1, float by1, float bz1,
-                                         V3 idir, V3 oid, SlabSigns neg, float slack, float tn_min, float tn_max, float& t_enter) {
+                                         V3 idir, V3 oid_in, V3 oid_out, SlabSigns neg, float tn_min, float tn_max, float& t_enter) {
     return box_planes(neg.x ? bx1 : bx0, neg.y ? by1 : by0, neg.z ? bz1 : bz0, neg.x ? bx0 : bx1, neg.y ? by0 : by1, neg.z ? bz0 : bz1,
-                      idir, oid, slack, tn_min, tn_max, t_enter);
+                      idir, oid_in, oid_out, tn_min, tn_max, t_enter);
 }
 
 // Per-ray constants of the slab test.  A direction component of zero (or too small for a finite
 // reciprocal) takes +-1e30 as its reciprocal: the two plane distances of that axis then come out
 // as huge numbers of opposite sign when the origin lies between the planes and of equal sign when
-// it does not, which is the answer for a ray parallel to the slab.  (With an infinite reciprocal
-// b * inf - o * inf is NaN whenever b and o have the same sign.)
-struct SlabRay { V3 idir, oid; SlabSigns neg; float slack; };
+// it does not, which is the answer for a ray parallel to the slab (no error term there: the signs
+// decide).  (With an infinite reciprocal b * inf - o * inf is NaN whenever b and o have the same
+// sign.)
+struct SlabRay { V3 idir, oid, oid_in, oid_out; SlabSigns neg; };
+__device__ __forceinline__ float slab_margin(float idir, float size) {
+    const float e = fabsf(idir) < 1.0e30f ? size : 0.0f;
+    return isfinite(e) ? e : 0.0f;
+}
 __device__ __forceinline__ SlabRay slab_ray(V3 o, V3 dh) {
     SlabRay r;
     const float lim = 1.0e30f;
     r.idir = mk(fminf(fmaxf(__builtin_amdgcn_rcpf(dh.x), -lim), lim), fminf(fmaxf(__builtin_amdgcn_rcpf(dh.y), -lim), lim),
                 fminf(fmaxf(__builtin_amdgcn_rcpf(dh.z), -lim), lim));
-    r.oid = mk(-o.x * r.idir.x, -o.y * r.idir.y, -o.z * r.idir.z);
+    const V3 oid = mk(-o.x * r.idir.x, -o.y * r.idir.y, -o.z * r.idir.z);
+    r.oid = oid;
     r.neg.x = r.idir.x < 0.0f; r.neg.y = r.idir.y < 0.0f; r.neg.z = r.idir.z < 0.0f;
-    // rounding error bound of the fused form, from the axes the ray actually moves along
-    float bx = fabsf(r.idir.x) < lim ? fabsf(r.oid.x) : 0.0f, by = fabsf(r.idir.y) < lim ? fabsf(r.oid.y) : 0.0f,
-          bz = fabsf(r.idir.z) < lim ? fabsf(r.oid.z) : 0.0f;
-    float big = fmaxf(fmaxf(bx, by), bz);
-    r.slack = isfinite(big) ? 4.0e-7f * big : 0.0f;
+    const float ex = slab_margin(r.idir.x, 4.0e-7f * fabsf(oid.x)), ey = slab_margin(r.idir.y, 4.0e-7f * fabsf(oid.y)),
+                ez = slab_margin(r.idir.z, 4.0e-7f * fabsf(oid.z));
+    r.oid_in = mk(oid.x - ex, oid.y - ey, oid.z - ez);
+    r.oid_out = mk(oid.x + ex, oid.y + ey, oid.z + ez);
     return r;
 }
 
@@ -473,21 +482,19 @@ __device__ __forceinline__ void hit_bvh(const G& geo, V3 o, const RayN& rn, Orig
     // quantised nodes: a plane is lo + k * step, so its distance along the ray is k * (step / d) +
     // (lo - o) / d: grid origin and step are folded into the ray's constants, and the plane a ray
     // enters through is the low or the high half of a dword by the sign of its direction
-    V3 qa = mk(0.0f, 0.0f, 0.0f), qb = mk(0.0f, 0.0f, 0.0f);
+    V3 qa = mk(0.0f, 0.0f, 0.0f), qb_in = mk(0.0f, 0.0f, 0.0f), qb_out = mk(0.0f, 0.0f, 0.0f);
     unsigned sh_x = 0u, sh_y = 0u, sh_z = 0u;
-    float slack_q = 0.0f;
     if constexpr (G::kQuant) {
         qa = mk(geo.step[0] * sr.idir.x, geo.step[1] * sr.idir.y, geo.step[2] * sr.idir.z);
-        qb = mk(fmaf(geo.lo[0], sr.idir.x, sr.oid.x), fmaf(geo.lo[1], sr.idir.y, sr.oid.y), fmaf(geo.lo[2], sr.idir.z, sr.oid.z));
+        const V3 oid = sr.oid;
+        const V3 qb = mk(fmaf(geo.lo[0], sr.idir.x, oid.x), fmaf(geo.lo[1], sr.idir.y, oid.y), fmaf(geo.lo[2], sr.idir.z, oid.z));
         sh_x = sr.neg.x ? 16u : 0u; sh_y = sr.neg.y ? 16u : 0u; sh_z = sr.neg.z ? 16u : 0u;
-        // rounding error bound of k * qa + qb, from the sizes of the terms that were added up
-        // (an axis the ray does not move along has a reciprocal of 1e30 and decides by sign alone)
-        const float lim = 1.0e30f;
-        const float mx = fabsf(sr.idir.x) < lim ? fabsf(sr.oid.x) + fabsf(geo.lo[0] * sr.idir.x) + 65536.0f * fabsf(qa.x) : 0.0f;
-        const float my = fabsf(sr.idir.y) < lim ? fabsf(sr.oid.y) + fabsf(geo.lo[1] * sr.idir.y) + 65536.0f * fabsf(qa.y) : 0.0f;
-        const float mz = fabsf(sr.idir.z) < lim ? fabsf(sr.oid.z) + fabsf(geo.lo[2] * sr.idir.z) + 65536.0f * fabsf(qa.z) : 0.0f;
-        const float big = fmaxf(fmaxf(mx, my), mz);
-        slack_q = isfinite(big) ? 8.0e-7f * big : 0.0f;
+        // rounding error bound of k * qa + qb per axis, from the sizes of the terms that were added up
+        const float ex = slab_margin(sr.idir.x, 8.0e-7f * (fabsf(oid.x) + fabsf(geo.lo[0] * sr.idir.x) + 65536.0f * fabsf(qa.x)));
+        const float ey = slab_margin(sr.idir.y, 8.0e-7f * (fabsf(oid.y) + fabsf(geo.lo[1] * sr.idir.y) + 65536.0f * fabsf(qa.y)));
+        const float ez = slab_margin(sr.idir.z, 8.0e-7f * (fabsf(oid.z) + fabsf(geo.lo[2] * sr.idir.z) + 65536.0f * fabsf(qa.z)));
+        qb_in = mk(qb.x - ex, qb.y - ey, qb.z - ez);
+        qb_out = mk(qb.x + ex, qb.y + ey, qb.z + ez);
     }
     // the stack top as an LDS byte address: a push or pop is one add and one LDS access
     constexpr unsigned kStackStride = kBlock * sizeof(int);
@@ -517,24 +524,24 @@ __device__ __forceinline__ void hit_bvh(const G& geo, V3 o, const RayN& rn, Orig
                 lds_cfloat* ez = (lds_cfloat*)(size_t)az; lds_cfloat* lz = (lds_cfloat*)(size_t)(az ^ 4u);
                 lds_cint* refs = (lds_cint*)(size_t)((unsigned)cur + 48u);
                 left = refs[0]; right = refs[1];
-                hl = box_planes(ex[0], ey[0], ez[0], lx[0], ly[0], lz[0], sr.idir, sr.oid, sr.slack, tn_min, best.tn, tl);
-                hr = box_planes(ex[2], ey[2], ez[2], lx[2], ly[2], lz[2], sr.idir, sr.oid, sr.slack, tn_min, best.tn, tr);
+                hl = box_planes(ex[0], ey[0], ez[0], lx[0], ly[0], lz[0], sr.idir, sr.oid_in, sr.oid_out, tn_min, best.tn, tl);
+                hr = box_planes(ex[2], ey[2], ez[2], lx[2], ly[2], lz[2], sr.idir, sr.oid_in, sr.oid_out, tn_min, best.tn, tr);
             } else if constexpr (G::kQuant) {
                 const uint4 a = geo.qnode(cur, 0), b = geo.qnode(cur, 1);
                 left = (int)b.z; right = (int)b.w;
 #define RT_QPLANE(word, shift) ((float)__builtin_amdgcn_ubfe((word), (shift), 16u))
                 hl = box_planes(RT_QPLANE(a.x, sh_x), RT_QPLANE(a.y, sh_y), RT_QPLANE(a.z, sh_z),
                                 RT_QPLANE(a.x, sh_x ^ 16u), RT_QPLANE(a.y, sh_y ^ 16u), RT_QPLANE(a.z, sh_z ^ 16u),
-                                qa, qb, slack_q, tn_min, best.tn, tl);
+                                qa, qb_in, qb_out, tn_min, best.tn, tl);
                 hr = box_planes(RT_QPLANE(a.w, sh_x), RT_QPLANE(b.x, sh_y), RT_QPLANE(b.y, sh_z),
                                 RT_QPLANE(a.w, sh_x ^ 16u), RT_QPLANE(b.x, sh_y ^ 16u), RT_QPLANE(b.y, sh_z ^ 16u),
-                                qa, qb, slack_q, tn_min, best.tn, tr);
+                                qa, qb_in, qb_out, tn_min, best.tn, tr);
 #undef RT_QPLANE
             } else {
                 float4 q0 = geo.node(cur, 0), q1 = geo.node(cur, 1), q2 = geo.node(cur, 2), q3 = geo.node(cur, 3);
                 left = __float_as_int(q3.x); right = __float_as_int(q3.y);
-                hl = box_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, sr.idir, sr.oid, sr.neg, sr.slack, tn_min, best.tn, tl);
-                hr = box_test(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, sr.idir, sr.oid, sr.neg, sr.slack, tn_min, best.tn, tr);
+                hl = box_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, sr.idir, sr.oid_in, sr.oid_out, sr.neg, tn_min, best.tn, tl);
+                hr = box_test(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, sr.idir, sr.oid_in, sr.oid_out, sr.neg, tn_min, best.tn, tr);
             }
             // (a straight-line version of this step, with selects and unconditional stack traffic,
             // measured 1 % slower)
