@@ -520,7 +520,7 @@ int rt_upload_scene(rt_context* ctx, const rt_scene_desc* d) {
         break;
     }
     ctx->coarse_nodes = 0;
-    if (use_bvh && n_nodes > 0 && root >= 0 && root != rt::kNoBvh) {
+    if (use_bvh && n_nodes > 0 && n_nodes < (1 << 27) && root >= 0 && root != rt::kNoBvh) {
         // 32-byte nodes for walks out of HBM: planes on a 16-bit grid over the root's box
         float rn[16];
         RT_HIP(ctx, hipMemcpy(rn, s.nodes + 4 * (size_t)root, sizeof(rn), hipMemcpyDeviceToHost));

@@ -190,6 +190,9 @@ __device__ __forceinline__ bool rect_test(const DRect& r, float num, V3 o, V3 d,
 // but a wave waits for its slowest lane.
 struct SlabSigns { bool x, y, z; };                    // direction component negative
 // the test proper, from the three planes the ray enters through and the three it leaves through
+// (REL: the exit distance is also widened by a few ulps, for the reciprocals of the three axes
+// being off by an ulp each; not needed where the margins in oid_in / oid_out cover that as well)
+template <bool REL = true>
 __device__ __forceinline__ bool box_planes(float enter_x, float enter_y, float enter_z, float leave_x, float leave_y, float leave_z,
                                            V3 idir, V3 oid_in, V3 oid_out, float tn_min, float tn_max, float& t_enter) {
     float nx = fmaf(enter_x, idir.x, oid_in.x), fx = fmaf(leave_x, idir.x, oid_out.x);
@@ -198,12 +201,24 @@ __device__ __forceinline__ bool box_planes(float enter_x, float enter_y, float e
     float tnear = fmaxf(fmaxf(fmaxf(nx, ny), nz), tn_min);
     float tfar = fminf(fminf(fminf(fx, fy), fz), tn_max);
     t_enter = tnear;
-    return tnear <= tfar * 1.0000005f;
+    return tnear <= (REL ? tfar * 1.0000005f : tfar);
 }
 __device__ __forceinline__ bool box_test(float bx0, float by0, float bz0, float bx1, float by1, float bz1,
                                          V3 idir, V3 oid_in, V3 oid_out, SlabSigns neg, float tn_min, float tn_max, float& t_enter) {
     return box_planes(neg.x ? bx1 : bx0, neg.y ? by1 : by0, neg.z ? bz1 : bz0, neg.x ? bx0 : bx1, neg.y ? by0 : by1, neg.z ? bz0 : bz1,
                       idir, oid_in, oid_out, tn_min, tn_max, t_enter);
+}
+
+// the low / high 16 bits of a dword as a float, in one instruction
+__device__ __forceinline__ float half_lo(unsigned w) {
+    float f;
+    asm("v_cvt_f32_u32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0" : "=v"(f) : "v"(w));
+    return f;
+}
+__device__ __forceinline__ float half_hi(unsigned w) {
+    float f;
+    asm("v_cvt_f32_u32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(f) : "v"(w));
+    return f;
 }
 
 // Per-ray constants of the slab test.  A direction component of zero (or too small for a finite
@@ -255,7 +270,11 @@ struct GeoGlobalQ {
     const uint4* qnodes; const float4* sph; const int2* info;
     float lo[3], step[3];
     __device__ __forceinline__ int root_ref(int root) const { return root; }
-    __device__ __forceinline__ uint4 qnode(int i, int q) const { return qnodes[2 * (size_t)i + q]; }
+    // (32-bit byte offset from a uniform base: one shift per step instead of 64-bit address
+    // arithmetic; the quantised form is only made for trees of fewer than 2^27 nodes)
+    __device__ __forceinline__ uint4 qnode(int i, int q) const {
+        return *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(qnodes) + (((unsigned)i << 5) + 16u * q));
+    }
     __device__ __forceinline__ float4 sphere(int i) const { return sph[i]; }
     __device__ __forceinline__ int obj(int i) const { return info[i].x; }
     __device__ __forceinline__ int mat(int i) const { return info[i].y; }
@@ -489,10 +508,11 @@ __device__ __forceinline__ void hit_bvh(const G& geo, V3 o, const RayN& rn, Orig
         const V3 oid = sr.oid;
         const V3 qb = mk(fmaf(geo.lo[0], sr.idir.x, oid.x), fmaf(geo.lo[1], sr.idir.y, oid.y), fmaf(geo.lo[2], sr.idir.z, oid.z));
         sh_x = sr.neg.x ? 16u : 0u; sh_y = sr.neg.y ? 16u : 0u; sh_z = sr.neg.z ? 16u : 0u;
-        // rounding error bound of k * qa + qb per axis, from the sizes of the terms that were added up
-        const float ex = slab_margin(sr.idir.x, 8.0e-7f * (fabsf(oid.x) + fabsf(geo.lo[0] * sr.idir.x) + 65536.0f * fabsf(qa.x)));
-        const float ey = slab_margin(sr.idir.y, 8.0e-7f * (fabsf(oid.y) + fabsf(geo.lo[1] * sr.idir.y) + 65536.0f * fabsf(qa.y)));
-        const float ez = slab_margin(sr.idir.z, 8.0e-7f * (fabsf(oid.z) + fabsf(geo.lo[2] * sr.idir.z) + 65536.0f * fabsf(qa.z)));
+        // rounding error bound of k * qa + qb per axis, from the sizes of the terms that were added up,
+        // plus 6e-7 of the largest distance there can be for the reciprocals being an ulp off
+        const float ex = slab_margin(sr.idir.x, 1.4e-6f * (fabsf(oid.x) + fabsf(geo.lo[0] * sr.idir.x) + 65536.0f * fabsf(qa.x)));
+        const float ey = slab_margin(sr.idir.y, 1.4e-6f * (fabsf(oid.y) + fabsf(geo.lo[1] * sr.idir.y) + 65536.0f * fabsf(qa.y)));
+        const float ez = slab_margin(sr.idir.z, 1.4e-6f * (fabsf(oid.z) + fabsf(geo.lo[2] * sr.idir.z) + 65536.0f * fabsf(qa.z)));
         qb_in = mk(qb.x - ex, qb.y - ey, qb.z - ez);
         qb_out = mk(qb.x + ex, qb.y + ey, qb.z + ez);
     }
@@ -529,14 +549,14 @@ __device__ __forceinline__ void hit_bvh(const G& geo, V3 o, const RayN& rn, Orig
             } else if constexpr (G::kQuant) {
                 const uint4 a = geo.qnode(cur, 0), b = geo.qnode(cur, 1);
                 left = (int)b.z; right = (int)b.w;
-#define RT_QPLANE(word, shift) ((float)__builtin_amdgcn_ubfe((word), (shift), 16u))
-                hl = box_planes(RT_QPLANE(a.x, sh_x), RT_QPLANE(a.y, sh_y), RT_QPLANE(a.z, sh_z),
-                                RT_QPLANE(a.x, sh_x ^ 16u), RT_QPLANE(a.y, sh_y ^ 16u), RT_QPLANE(a.z, sh_z ^ 16u),
-                                qa, qb_in, qb_out, tn_min, best.tn, tl);
-                hr = box_planes(RT_QPLANE(a.w, sh_x), RT_QPLANE(b.x, sh_y), RT_QPLANE(b.y, sh_z),
-                                RT_QPLANE(a.w, sh_x ^ 16u), RT_QPLANE(b.x, sh_y ^ 16u), RT_QPLANE(b.y, sh_z ^ 16u),
-                                qa, qb_in, qb_out, tn_min, best.tn, tr);
-#undef RT_QPLANE
+                // per dword one rotation by the ray's shift (0 or 16) puts the plane the ray enters
+                // through into the low half; the halves are converted straight out of the dword
+                // (sub-dword operand select), three instructions per axis and box
+                const unsigned lx = __builtin_amdgcn_alignbit(a.x, a.x, sh_x), ly = __builtin_amdgcn_alignbit(a.y, a.y, sh_y),
+                               lz = __builtin_amdgcn_alignbit(a.z, a.z, sh_z), rx = __builtin_amdgcn_alignbit(a.w, a.w, sh_x),
+                               ry = __builtin_amdgcn_alignbit(b.x, b.x, sh_y), rz = __builtin_amdgcn_alignbit(b.y, b.y, sh_z);
+                hl = box_planes<false>(half_lo(lx), half_lo(ly), half_lo(lz), half_hi(lx), half_hi(ly), half_hi(lz), qa, qb_in, qb_out, tn_min, best.tn, tl);
+                hr = box_planes<false>(half_lo(rx), half_lo(ry), half_lo(rz), half_hi(rx), half_hi(ry), half_hi(rz), qa, qb_in, qb_out, tn_min, best.tn, tr);
             } else {
                 float4 q0 = geo.node(cur, 0), q1 = geo.node(cur, 1), q2 = geo.node(cur, 2), q3 = geo.node(cur, 3);
                 left = __float_as_int(q3.x); right = __float_as_int(q3.y);
