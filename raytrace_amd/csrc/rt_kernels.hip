@@ -319,14 +319,17 @@ template <bool COUNT, class G>
 __device__ __forceinline__ void leaf_spheres(const G& geo, int first, int count, V3 o, V3 dh,
                                              float tn_min, int self, Cand& best, Counters& cn) {
     if constexpr (G::kPrefetchLeaf) {
-        // geometry in HBM: the leaf's (up to) four records are requested together, so that a leaf
-        // costs one memory round trip, not one per sphere (the arrays are padded for the reads
-        // past a shorter leaf)
-        float4 s0 = geo.sphere(first), s1 = geo.sphere(first + 1), s2 = geo.sphere(first + 2), s3 = geo.sphere(first + 3);
+        // geometry in HBM: a leaf's records are requested two at a time, so that a leaf of one or
+        // two spheres (most leaves of a large scene) costs one memory round trip and two tag
+        // lookups per lane (the arrays are padded for the reads past a shorter leaf)
+        float4 s0 = geo.sphere(first), s1 = geo.sphere(first + 1);
         leaf_sphere<COUNT>(geo, first, s0, o, dh, tn_min, self, best, cn);
         if (count > 1) leaf_sphere<COUNT>(geo, first + 1, s1, o, dh, tn_min, self, best, cn);
-        if (count > 2) leaf_sphere<COUNT>(geo, first + 2, s2, o, dh, tn_min, self, best, cn);
-        if (count > 3) leaf_sphere<COUNT>(geo, first + 3, s3, o, dh, tn_min, self, best, cn);
+        if (count > 2) {
+            float4 s2 = geo.sphere(first + 2), s3 = geo.sphere(first + 3);
+            leaf_sphere<COUNT>(geo, first + 2, s2, o, dh, tn_min, self, best, cn);
+            if (count > 3) leaf_sphere<COUNT>(geo, first + 3, s3, o, dh, tn_min, self, best, cn);
+        }
         for (int i = first + 4; i < first + count; i++) leaf_sphere<COUNT>(geo, i, geo.sphere(i), o, dh, tn_min, self, best, cn);
     } else {
         for (int i = first; i < first + count; i++) leaf_sphere<COUNT>(geo, i, geo.sphere(i), o, dh, tn_min, self, best, cn);
