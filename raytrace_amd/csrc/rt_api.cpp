@@ -525,18 +525,21 @@ int rt_upload_scene(rt_context* ctx, const rt_scene_desc* d) {
         break;
     }
     ctx->coarse_nodes = 0;
-    if (use_bvh && n_nodes > 0 && n_nodes < (1 << 27) && root >= 0 && root != rt::kNoBvh) {
-        // 32-byte nodes for walks out of HBM: planes on a 16-bit grid over the root's box
+    if (use_bvh && n_nodes > 0 && root >= 0 && root != rt::kNoBvh) {
+        // the root's two boxes span the tree
         float rn[16];
         RT_HIP(ctx, hipMemcpy(rn, s.nodes + 4 * (size_t)root, sizeof(rn), hipMemcpyDeviceToHost));
-        float lo[3], step[3];
         for (int a = 0; a < 3; a++) {
             const float l = std::fmin(rn[a], rn[6 + a]), h = std::fmax(rn[3 + a], rn[9 + a]);
-            lo[a] = l;
-            step[a] = (float)(((double)h - (double)l) * (1.0 + 1e-6) / 65535.0);
-            if (!(step[a] > 0.0f) || !std::isfinite(step[a])) step[a] = 1e-30f;
-            s.q_lo[a] = lo[a]; s.q_step[a] = step[a];
+            s.tree_reach[a] = std::fmax(std::fabs(l), std::fabs(h));
+            float step = (float)(((double)h - (double)l) * (1.0 + 1e-6) / 65535.0);
+            if (!(step > 0.0f) || !std::isfinite(step)) step = 1e-30f;
+            s.q_lo[a] = l; s.q_step[a] = step;
         }
+    }
+    if (use_bvh && n_nodes > 0 && n_nodes < (1 << 27) && root >= 0 && root != rt::kNoBvh) {
+        // 32-byte nodes for walks out of HBM: planes on a 16-bit grid over the root's box
+        float lo[3] = {s.q_lo[0], s.q_lo[1], s.q_lo[2]}, step[3] = {s.q_step[0], s.q_step[1], s.q_step[2]};
         void* qn = nullptr;
         RT_HIP(ctx, hipMalloc(&qn, (size_t)n_nodes * 32));
         ctx->scene_allocs.push_back(qn);

@@ -67,6 +67,7 @@ struct DScene {
     const float4* nodes;
     const uint4* qnodes;  // the same nodes in 32 bytes (16-bit planes on the grid q_lo + k * q_step), or null when the grid is too coarse for some node: what frames walk out of HBM
     float q_lo[3], q_step[3];
+    float tree_reach[3];  // largest |coordinate| of the tree's box planes, per axis (the slab test's rounding margins)
     int n_nodes;
     int root;             // inner index, leaf code, or kNoBvh
     int bvh_depth;

@@ -190,9 +190,6 @@ __device__ __forceinline__ bool rect_test(const DRect& r, float num, V3 o, V3 d,
 // but a wave waits for its slowest lane.
 struct SlabSigns { bool x, y, z; };                    // direction component negative
 // the test proper, from the three planes the ray enters through and the three it leaves through
-// (REL: the exit distance is also widened by a few ulps, for the reciprocals of the three axes
-// being off by an ulp each; not needed where the margins in oid_in / oid_out cover that as well)
-template <bool REL = true>
 __device__ __forceinline__ bool box_planes(float enter_x, float enter_y, float enter_z, float leave_x, float leave_y, float leave_z,
                                            V3 idir, V3 oid_in, V3 oid_out, float tn_min, float tn_max, float& t_enter) {
     float nx = fmaf(enter_x, idir.x, oid_in.x), fx = fmaf(leave_x, idir.x, oid_out.x);
@@ -201,7 +198,7 @@ __device__ __forceinline__ bool box_planes(float enter_x, float enter_y, float e
     float tnear = fmaxf(fmaxf(fmaxf(nx, ny), nz), tn_min);
     float tfar = fminf(fminf(fminf(fx, fy), fz), tn_max);
     t_enter = tnear;
-    return tnear <= (REL ? tfar * 1.0000005f : tfar);
+    return tnear <= tfar;
 }
 __device__ __forceinline__ bool box_test(float bx0, float by0, float bz0, float bx1, float by1, float bz1,
                                          V3 idir, V3 oid_in, V3 oid_out, SlabSigns neg, float tn_min, float tn_max, float& t_enter) {
@@ -232,7 +229,11 @@ __device__ __forceinline__ float slab_margin(float idir, float size) {
     const float e = fabsf(idir) < 1.0e30f ? size : 0.0f;
     return isfinite(e) ? e : 0.0f;
 }
-__device__ __forceinline__ SlabRay slab_ray(V3 o, V3 dh) {
+// reach: the largest |coordinate| of any box plane, per axis.  A plane distance is at most
+// reach * |1/d| + |o/d|; 6e-7 of that covers the reciprocals of the three axes being an ulp off each
+// (distances of different axes are compared with each other), 4e-7 of |o/d| the rounding of the
+// fused form.
+__device__ __forceinline__ SlabRay slab_ray(V3 o, V3 dh, V3 reach) {
     SlabRay r;
     const float lim = 1.0e30f;
     r.idir = mk(fminf(fmaxf(__builtin_amdgcn_rcpf(dh.x), -lim), lim), fminf(fmaxf(__builtin_amdgcn_rcpf(dh.y), -lim), lim),
@@ -240,8 +241,9 @@ __device__ __forceinline__ SlabRay slab_ray(V3 o, V3 dh) {
     const V3 oid = mk(-o.x * r.idir.x, -o.y * r.idir.y, -o.z * r.idir.z);
     r.oid = oid;
     r.neg.x = r.idir.x < 0.0f; r.neg.y = r.idir.y < 0.0f; r.neg.z = r.idir.z < 0.0f;
-    const float ex = slab_margin(r.idir.x, 4.0e-7f * fabsf(oid.x)), ey = slab_margin(r.idir.y, 4.0e-7f * fabsf(oid.y)),
-                ez = slab_margin(r.idir.z, 4.0e-7f * fabsf(oid.z));
+    const float ex = slab_margin(r.idir.x, fmaf(6.0e-7f * reach.x, fabsf(r.idir.x), 1.0e-6f * fabsf(oid.x))),
+                ey = slab_margin(r.idir.y, fmaf(6.0e-7f * reach.y, fabsf(r.idir.y), 1.0e-6f * fabsf(oid.y))),
+                ez = slab_margin(r.idir.z, fmaf(6.0e-7f * reach.z, fabsf(r.idir.z), 1.0e-6f * fabsf(oid.z)));
     r.oid_in = mk(oid.x - ex, oid.y - ey, oid.z - ez);
     r.oid_out = mk(oid.x + ex, oid.y + ey, oid.z + ez);
     return r;
@@ -254,6 +256,7 @@ struct GeoGlobal {
     static constexpr bool kPlaneAddressed = false;
     static constexpr bool kQuant = false;
     const float4* nodes; const float4* sph; const int2* info;
+    V3 reach;                                                    // largest |coordinate| of the tree's box planes, per axis
     __device__ __forceinline__ int root_ref(int root) const { return root; }
     __device__ __forceinline__ float4 node(int i, int q) const { return nodes[4 * (size_t)i + q]; }
     __device__ __forceinline__ float4 sphere(int i) const { return sph[i]; }
@@ -269,6 +272,7 @@ struct GeoGlobalQ {
     static constexpr bool kQuant = true;
     const uint4* qnodes; const float4* sph; const int2* info;
     float lo[3], step[3];
+    V3 reach;
     __device__ __forceinline__ int root_ref(int root) const { return root; }
     // (32-bit byte offset from a uniform base: one shift per step instead of 64-bit address
     // arithmetic; the quantised form is only made for trees of fewer than 2^27 nodes)
@@ -296,6 +300,7 @@ struct GeoLds {
     static constexpr bool kQuant = false;
     unsigned node_base;                                          // LDS byte address of node 0
     const float4* sph; const int* objs;                          // both point into LDS
+    V3 reach;
     __device__ __forceinline__ int root_ref(int root) const { return root >= 0 ? (int)node_base + (root << 6) : root; }   // a tiny scene's root is a leaf
     __device__ __forceinline__ float4 sphere(int i) const { return sph[i]; }
     // list position and material share a word (both below 65536 in a scene that fits in LDS)
@@ -494,7 +499,7 @@ __device__ __forceinline__ void hit_bvh(const G& geo, V3 o, const RayN& rn, Orig
     const V3 dh = rn.dh;
     const int self = from.sphere();
     const float tn_min = rn.tn_min;
-    const SlabRay sr = slab_ray(o, dh);
+    const SlabRay sr = slab_ray(o, dh, geo.reach);
     unsigned enter_x = 0u, enter_y = 0u, enter_z = 0u;    // plane-addressed nodes: where this ray's entry planes sit in a node
     if constexpr (G::kPlaneAddressed) {
         enter_x = sr.neg.x ? 4u : 0u;
@@ -558,8 +563,8 @@ __device__ __forceinline__ void hit_bvh(const G& geo, V3 o, const RayN& rn, Orig
                 const unsigned lx = __builtin_amdgcn_alignbit(a.x, a.x, sh_x), ly = __builtin_amdgcn_alignbit(a.y, a.y, sh_y),
                                lz = __builtin_amdgcn_alignbit(a.z, a.z, sh_z), rx = __builtin_amdgcn_alignbit(a.w, a.w, sh_x),
                                ry = __builtin_amdgcn_alignbit(b.x, b.x, sh_y), rz = __builtin_amdgcn_alignbit(b.y, b.y, sh_z);
-                hl = box_planes<false>(half_lo(lx), half_lo(ly), half_lo(lz), half_hi(lx), half_hi(ly), half_hi(lz), qa, qb_in, qb_out, tn_min, best.tn, tl);
-                hr = box_planes<false>(half_lo(rx), half_lo(ry), half_lo(rz), half_hi(rx), half_hi(ry), half_hi(rz), qa, qb_in, qb_out, tn_min, best.tn, tr);
+                hl = box_planes(half_lo(lx), half_lo(ly), half_lo(lz), half_hi(lx), half_hi(ly), half_hi(lz), qa, qb_in, qb_out, tn_min, best.tn, tl);
+                hr = box_planes(half_lo(rx), half_lo(ry), half_lo(rz), half_hi(rx), half_hi(ry), half_hi(rz), qa, qb_in, qb_out, tn_min, best.tn, tr);
             } else {
                 float4 q0 = geo.node(cur, 0), q1 = geo.node(cur, 1), q2 = geo.node(cur, 2), q3 = geo.node(cur, 3);
                 left = __float_as_int(q3.x); right = __float_as_int(q3.y);
@@ -614,7 +619,7 @@ __device__ __forceinline__ Cand closest_hit(const DScene& sc, V3 o, V3 d, float 
     Cand best = no_hit();
     RayN rn = normalise(d, t_min);
     hit_always<COUNT, true>(sc, o, d, rn, t_min, no_origin(), best, cn);
-    GeoGlobal geo = {sc.nodes, sc.sph, sc.sph_info};
+    GeoGlobal geo = {sc.nodes, sc.sph, sc.sph_info, mk(sc.tree_reach[0], sc.tree_reach[1], sc.tree_reach[2])};
     if (!sc.use_bvh) hit_list<COUNT, false>(sc, nullptr, o, rn, no_origin(), best, cn);
     else if (sc.root != kNoBvh) {
         int cur = sc.root, sp = 0;
@@ -1002,13 +1007,13 @@ __device__ __forceinline__ typename GeoOf<LDS, QUANT>::type stage_geometry(const
         }
         for (int i = threadIdx.x; i < sc.n_sph; i += kBlock) { sph[i] = sc.sph[i]; int2 f = sc.sph_info[i]; objs[i] = f.x | (f.y << 16); }
         for (int i = sc.n_sph + threadIdx.x; i < sc.n_sph_padded; i += kBlock) { sph[i] = sc.sph[i]; objs[i] = 0; }   // the scan's padding
-        GeoLds g = {base, sph, objs};
+        GeoLds g = {base, sph, objs, mk(sc.tree_reach[0], sc.tree_reach[1], sc.tree_reach[2])};
         return g;
     } else if constexpr (QUANT) {
-        GeoGlobalQ g = {sc.qnodes, sc.sph, sc.sph_info, {sc.q_lo[0], sc.q_lo[1], sc.q_lo[2]}, {sc.q_step[0], sc.q_step[1], sc.q_step[2]}};
+        GeoGlobalQ g = {sc.qnodes, sc.sph, sc.sph_info, {sc.q_lo[0], sc.q_lo[1], sc.q_lo[2]}, {sc.q_step[0], sc.q_step[1], sc.q_step[2]}, mk(sc.tree_reach[0], sc.tree_reach[1], sc.tree_reach[2])};
         return g;
     } else {
-        GeoGlobal g = {sc.nodes, sc.sph, sc.sph_info};
+        GeoGlobal g = {sc.nodes, sc.sph, sc.sph_info, mk(sc.tree_reach[0], sc.tree_reach[1], sc.tree_reach[2])};
         return g;
     }
 }
