@@ -283,14 +283,16 @@ struct GeoGlobalQ {
     __device__ __forceinline__ int obj(int i) const { return info[i].x; }
     __device__ __forceinline__ int mat(int i) const { return info[i].y; }
 };
-// The LDS copy of the nodes is laid out for the slab test: 64 bytes per node,
-//   [x: left lo, left hi, right lo, right hi][y: the same][z: the same][left ref, right ref, -, -]
+// The LDS copy of the nodes is laid out for the slab test: 80 bytes per node,
+//   [x: left lo, left hi, left lo, right lo, right hi, right lo][y: the same][z: the same][left ref, right ref]
 // so that the plane a ray enters a child's slab through sits at (axis base + 4 bytes if the
-// direction component is negative) and the plane it leaves through at that address with bit 2
-// flipped.  A lane reads the six planes of both children it needs through addresses that carry
-// its ray's signs, instead of reading all twelve and selecting; the selects were a fifth of the
-// node step's VALU time and LDS has bandwidth to spare.  Inner-node references are the nodes' LDS
-// byte addresses (node_base + index * 64), leaves keep their negative codes.
+// direction component is negative) and the plane it leaves through in the next word, whatever the
+// sign (the low plane is stored on both sides of the high one).  A lane reads the six planes of
+// both children it needs through three addresses that carry its ray's signs, instead of reading
+// all twelve and selecting; the selects were a fifth of the node step's VALU time and LDS has
+// bandwidth to spare.  Inner-node references are the nodes' LDS byte addresses in units of 16
+// bytes ((node_base + index * 80) / 16), leaves keep their negative codes.
+constexpr int kLdsNodeBytes = 80;
 typedef const float __attribute__((address_space(3))) lds_cfloat;
 typedef const int __attribute__((address_space(3))) lds_cint;
 typedef int __attribute__((address_space(3))) lds_int;
@@ -301,7 +303,7 @@ struct GeoLds {
     unsigned node_base;                                          // LDS byte address of node 0
     const float4* sph; const int* objs;                          // both point into LDS
     V3 reach;
-    __device__ __forceinline__ int root_ref(int root) const { return root >= 0 ? (int)node_base + (root << 6) : root; }   // a tiny scene's root is a leaf
+    __device__ __forceinline__ int root_ref(int root) const { return root >= 0 ? (int)((node_base + (unsigned)root * kLdsNodeBytes) >> 4) : root; }   // a tiny scene's root is a leaf
     __device__ __forceinline__ float4 sphere(int i) const { return sph[i]; }
     // list position and material share a word (both below 65536 in a scene that fits in LDS)
     __device__ __forceinline__ int obj(int i) const { return objs[i] & 0xffff; }
@@ -493,6 +495,16 @@ __device__ __forceinline__ void hit_own_sphere(const G& geo, V3 o, const RayN& r
 constexpr int kTravDone = (int)0x80000000;     // not a leaf code: ~kTravDone >> kLeafBits = 2^28 - 1 with count 8, and a leaf
                                                // holds at most four spheres of at most 2^28 (rt_upload_scene's limit)
 
+typedef short __attribute__((address_space(3))) lds_short;
+template <bool SHORT>
+__device__ __forceinline__ void push_ref(unsigned top, int ref) {
+    if constexpr (SHORT) *(lds_short*)(size_t)top = (short)ref; else *(lds_int*)(size_t)top = ref;
+}
+template <bool SHORT>
+__device__ __forceinline__ int pop_ref(unsigned top) {
+    if constexpr (SHORT) return (int)*(lds_short*)(size_t)top; else return *(lds_int*)(size_t)top;
+}
+
 template <bool COUNT, bool SLICED, class G>
 __device__ __forceinline__ void hit_bvh(const G& geo, V3 o, const RayN& rn, Origin from, int* stack, int budget, int quorum,
                                         int& cur, int& sp, Cand& best, Counters& cn) {
@@ -503,8 +515,8 @@ __device__ __forceinline__ void hit_bvh(const G& geo, V3 o, const RayN& rn, Orig
     unsigned enter_x = 0u, enter_y = 0u, enter_z = 0u;    // plane-addressed nodes: where this ray's entry planes sit in a node
     if constexpr (G::kPlaneAddressed) {
         enter_x = sr.neg.x ? 4u : 0u;
-        enter_y = sr.neg.y ? 20u : 16u;
-        enter_z = sr.neg.z ? 36u : 32u;
+        enter_y = sr.neg.y ? 28u : 24u;
+        enter_z = sr.neg.z ? 52u : 48u;
     }
     // quantised nodes: a plane is lo + k * step, so its distance along the ray is k * (step / d) +
     // (lo - o) / d: grid origin and step are folded into the ray's constants, and the plane a ray
@@ -524,8 +536,11 @@ __device__ __forceinline__ void hit_bvh(const G& geo, V3 o, const RayN& rn, Orig
         qb_in = mk(qb.x - ex, qb.y - ey, qb.z - ez);
         qb_out = mk(qb.x + ex, qb.y + ey, qb.z + ez);
     }
-    // the stack top as an LDS byte address: a push or pop is one add and one LDS access
-    constexpr unsigned kStackStride = kBlock * sizeof(int);
+    // the stack top as an LDS byte address: a push or pop is one add and one LDS access.  With
+    // the tree in LDS a reference fits 16 bits (a node's address in units of 16 bytes, or a leaf
+    // code over fewer than 4096 sphere slots): half the stack, which is what lets the 80-byte nodes
+    // in beside it at five workgroups per CU.
+    constexpr unsigned kStackStride = kBlock * (G::kPlaneAddressed ? sizeof(short) : sizeof(int));
     const unsigned bottom = (unsigned)(size_t)(__attribute__((address_space(3))) char*)stack;
     unsigned top = bottom + (unsigned)sp * kStackStride;
     int wave_steps = 0;
@@ -546,14 +561,18 @@ __device__ __forceinline__ void hit_bvh(const G& geo, V3 o, const RayN& rn, Orig
             bool hl, hr;
             if (COUNT) cn.box += 2;
             if constexpr (G::kPlaneAddressed) {
-                const unsigned ax = (unsigned)cur + enter_x, ay = (unsigned)cur + enter_y, az = (unsigned)cur + enter_z;
-                lds_cfloat* ex = (lds_cfloat*)(size_t)ax; lds_cfloat* lx = (lds_cfloat*)(size_t)(ax ^ 4u);
-                lds_cfloat* ey = (lds_cfloat*)(size_t)ay; lds_cfloat* ly = (lds_cfloat*)(size_t)(ay ^ 4u);
-                lds_cfloat* ez = (lds_cfloat*)(size_t)az; lds_cfloat* lz = (lds_cfloat*)(size_t)(az ^ 4u);
-                lds_cint* refs = (lds_cint*)(size_t)((unsigned)cur + 48u);
+                // per axis: words 0 and 3 from the ray's address are the planes it enters the left and
+                // the right child through, words 1 and 4 the ones it leaves through
+                lds_cfloat* px = (lds_cfloat*)(size_t)(((unsigned)cur << 4) + enter_x);
+                lds_cfloat* py = (lds_cfloat*)(size_t)(((unsigned)cur << 4) + enter_y);
+                lds_cfloat* pz = (lds_cfloat*)(size_t)(((unsigned)cur << 4) + enter_z);
+                lds_cint* refs = (lds_cint*)(size_t)(((unsigned)cur << 4) + 72u);
                 left = refs[0]; right = refs[1];
-                hl = box_planes(ex[0], ey[0], ez[0], lx[0], ly[0], lz[0], sr.idir, sr.oid_in, sr.oid_out, tn_min, best.tn, tl);
-                hr = box_planes(ex[2], ey[2], ez[2], lx[2], ly[2], lz[2], sr.idir, sr.oid_in, sr.oid_out, tn_min, best.tn, tr);
+                float l_ex = px[0], r_ex = px[3], l_lx = px[1], r_lx = px[4];
+                float l_ey = py[0], r_ey = py[3], l_ly = py[1], r_ly = py[4];
+                float l_ez = pz[0], r_ez = pz[3], l_lz = pz[1], r_lz = pz[4];
+                hl = box_planes(l_ex, l_ey, l_ez, l_lx, l_ly, l_lz, sr.idir, sr.oid_in, sr.oid_out, tn_min, best.tn, tl);
+                hr = box_planes(r_ex, r_ey, r_ez, r_lx, r_ly, r_lz, sr.idir, sr.oid_in, sr.oid_out, tn_min, best.tn, tr);
             } else if constexpr (G::kQuant) {
                 const uint4 a = geo.qnode(cur, 0), b = geo.qnode(cur, 1);
                 left = (int)b.z; right = (int)b.w;
@@ -575,14 +594,14 @@ __device__ __forceinline__ void hit_bvh(const G& geo, V3 o, const RayN& rn, Orig
             // measured 1 % slower)
             if (hl && hr) {
                 bool left_first = tl <= tr;
-                *(lds_int*)(size_t)top = left_first ? right : left;
+                push_ref<G::kPlaneAddressed>(top, left_first ? right : left);
                 top += kStackStride;
                 cur = left_first ? left : right;
             } else if (hl || hr) {
                 cur = hl ? left : right;
             } else if (top != bottom) {
                 top -= kStackStride;
-                cur = *(lds_int*)(size_t)top;
+                cur = pop_ref<G::kPlaneAddressed>(top);
             } else {
                 cur = kTravDone;
             }
@@ -604,7 +623,7 @@ __device__ __forceinline__ void hit_bvh(const G& geo, V3 o, const RayN& rn, Orig
             leaf_spheres<COUNT>(geo, code >> kLeafBits, (code & (kLeafCap - 1)) + 1, o, dh, tn_min, self, best, cn);
             if (top != bottom) {
                 top -= kStackStride;
-                cur = *(lds_int*)(size_t)top;
+                cur = pop_ref<G::kPlaneAddressed>(top);
             } else {
                 cur = kTravDone;
             }
@@ -992,18 +1011,20 @@ struct GeoOf<true, QUANT> { using type = GeoLds; };
 template <bool LDS, bool QUANT>
 __device__ __forceinline__ typename GeoOf<LDS, QUANT>::type stage_geometry(const DScene& sc, int* lds) {
     if constexpr (LDS) {
-        float4* nodes = reinterpret_cast<float4*>(lds);
-        float4* sph = nodes + 4 * sc.n_nodes;
+        float* nodes = reinterpret_cast<float*>(lds);
+        float4* sph = reinterpret_cast<float4*>(nodes + (kLdsNodeBytes / 4) * sc.n_nodes);
         int* objs = reinterpret_cast<int*>(sph + sc.n_sph_padded);
         const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)nodes;
         for (int i = threadIdx.x; i < sc.n_nodes; i += kBlock) {
             // device layout: left box lo xyz, hi xyz, right box lo xyz, hi xyz, left, right
             const float4 q0 = sc.nodes[4 * i], q1 = sc.nodes[4 * i + 1], q2 = sc.nodes[4 * i + 2], q3 = sc.nodes[4 * i + 3];
             const int l = __float_as_int(q3.x), r = __float_as_int(q3.y);
-            nodes[4 * i + 0] = make_float4(q0.x, q0.w, q1.z, q2.y);
-            nodes[4 * i + 1] = make_float4(q0.y, q1.x, q1.w, q2.z);
-            nodes[4 * i + 2] = make_float4(q0.z, q1.y, q2.x, q2.w);
-            nodes[4 * i + 3] = make_float4(__int_as_float(l >= 0 ? (int)base + (l << 6) : l), __int_as_float(r >= 0 ? (int)base + (r << 6) : r), 0.0f, 0.0f);
+            float* n = nodes + (kLdsNodeBytes / 4) * i;
+            n[0] = q0.x; n[1] = q0.w; n[2] = q0.x; n[3] = q1.z; n[4] = q2.y; n[5] = q1.z;
+            n[6] = q0.y; n[7] = q1.x; n[8] = q0.y; n[9] = q1.w; n[10] = q2.z; n[11] = q1.w;
+            n[12] = q0.z; n[13] = q1.y; n[14] = q0.z; n[15] = q2.x; n[16] = q2.w; n[17] = q2.x;
+            n[18] = __int_as_float(l >= 0 ? (int)((base + (unsigned)l * kLdsNodeBytes) >> 4) : l);
+            n[19] = __int_as_float(r >= 0 ? (int)((base + (unsigned)r * kLdsNodeBytes) >> 4) : r);
         }
         for (int i = threadIdx.x; i < sc.n_sph; i += kBlock) { sph[i] = sc.sph[i]; int2 f = sc.sph_info[i]; objs[i] = f.x | (f.y << 16); }
         for (int i = sc.n_sph + threadIdx.x; i < sc.n_sph_padded; i += kBlock) { sph[i] = sc.sph[i]; objs[i] = 0; }   // the scan's padding
@@ -1047,7 +1068,8 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? RT_WG_PER_CU_SCAN : RT_WG_PER_C
                                                         unsigned long long* __restrict__ counters) {
     constexpr bool SLICED = MODE == 2, BVH = MODE != 0;
     extern __shared__ __align__(16) int s_dyn[];
-    int* stack = s_dyn + threadIdx.x;
+    // (16-bit entries with the tree in LDS: see hit_bvh)
+    int* stack = (LDS && MODE != 0) ? reinterpret_cast<int*>(reinterpret_cast<short*>(s_dyn) + threadIdx.x) : s_dyn + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const int P = 64 / rp.lanes_per_pixel;             // pixels of this wave's tile
     // per wave: two tiles in flight (the one whose units are being handed out and the one before
@@ -1330,16 +1352,22 @@ hipError_t launch_render(const DScene& sc, const DCamera& cam, const DRender& rp
     // when it all fits in a budget that still leaves four workgroups per CU, a copy of the BVH
     // and the sphere list
     DRender r = rp;
-    r.stack_depth = sc.use_bvh ? sc.bvh_depth + 1 : 1;   // one push per inner level at most
-    size_t lds = (size_t)r.stack_depth * kBlock * sizeof(int) + (size_t)(kBlock / 64) * (8 * (64 / rp.lanes_per_pixel) + 1) * sizeof(unsigned long long);
-    const size_t geo_bytes = (size_t)sc.n_nodes * 64 + (size_t)sc.n_sph_padded * 20;
-    // the tree walk keeps tree and spheres in LDS up to 40 KB per workgroup.  The scan reads a
+    // one push per inner level at most; stack_depth is in units of kBlock ints
+    const int entries = sc.use_bvh ? sc.bvh_depth + 1 : 1;
+    const size_t accum_bytes = (size_t)(kBlock / 64) * (8 * (64 / rp.lanes_per_pixel) + 1) * sizeof(unsigned long long);
+    const size_t geo_bytes = (size_t)sc.n_nodes * kLdsNodeBytes + (size_t)sc.n_sph_padded * 20;
+    // the tree walk keeps tree and spheres in LDS up to 40 KB per workgroup (its stack then holds
+    // 16-bit references).  The scan reads a
     // short list (a room with a few balls) from LDS: 6 % faster than through scalar loads, whose
     // latency a loop of one or two trips cannot hide; a long list is faster through scalar loads
     // (487 spheres: by 6 %), which run ahead of the arithmetic and cost no vector registers
+    const int short_depth = (entries + 1) / 2;
     const bool in_lds = (rp.flags & 32u) == 0u && sc.n_sph > 0 &&
                         sc.ids_fit_16 &&                  // the LDS copy packs list position and material into one word
-                        (sc.use_bvh ? lds + geo_bytes <= 40 * 1024 : sc.n_sph_padded <= 32);
+                        (sc.use_bvh ? sc.n_sph_padded + 8 < 4096 && (size_t)short_depth * kBlock * sizeof(int) + accum_bytes + geo_bytes <= 40 * 1024
+                                    : sc.n_sph_padded <= 32);
+    r.stack_depth = (in_lds && sc.use_bvh) ? short_depth : entries;
+    size_t lds = (size_t)r.stack_depth * kBlock * sizeof(int) + accum_bytes;
     if (in_lds) lds += geo_bytes;
     const bool count = (rp.flags & 4u) != 0u;
     const bool prof = (rp.flags & 8u) != 0u;
