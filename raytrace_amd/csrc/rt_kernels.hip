@@ -164,10 +164,18 @@ __device__ __forceinline__ V3 to_world_dir(const DXform& x, V3 v) {
 }
 
 // cuda/rect.h:29-52 (xy), 75-99 (xz), 122-146 (yz); parametric t; num = k - origin along the
-// plane's axis.  A ray parallel to the plane never hits.
-__device__ __forceinline__ bool rect_test(const DRect& r, float num, V3 o, V3 d, float t_min, float t_max, float& t_out) {
-    int ka = r.axes & 3, aa = (r.axes >> 2) & 3, ba = (r.axes >> 4) & 3;
-    float t = num / comp(d, ka);
+// plane's axis, inv = 1 / direction along that axis (polished_rcp: a division costs ten
+// instructions per rect, the reciprocals three per ray and axis).  A ray parallel to the plane never
+// hits (inv is then NaN).
+__device__ __forceinline__ float polished_rcp(float x) {
+    const float r = __builtin_amdgcn_rcpf(x);
+    return fmaf(fmaf(-x, r, 1.0f), r, r);
+}
+// KA: the plane's axis; the in-plane axes follow from it (yz: y, z; xz: x, z; xy: x, y).
+template <int KA>
+__device__ __forceinline__ bool rect_test(const DRect& r, float num, float inv, V3 o, V3 d, float t_min, float t_max, float& t_out) {
+    constexpr int aa = KA == 0 ? 1 : 0, ba = KA == 2 ? 1 : 2;
+    float t = num * inv;
     if (!(t >= t_min && t <= t_max)) return false;
     float av = fmaf(t, comp(d, aa), comp(o, aa));
     float bv = fmaf(t, comp(d, ba), comp(o, ba));
@@ -385,6 +393,9 @@ __device__ __forceinline__ void hit_always(const DScene& sc, V3 o, V3 d, const R
             best.tn = tn; best.kind = 1; best.idx = i; best.obj = w.obj;
         }
     }
+    V3 inv_d = mk(0.0f, 0.0f, 0.0f);
+    if constexpr (RECTS)
+        if (sc.n_rects > 0) inv_d = mk(polished_rcp(d.x), polished_rcp(d.y), polished_rcp(d.z));
     if constexpr (RECTS)
     for (int i = 0; i < sc.n_rects; i++) {
         const DRect r = sc.rects[i];
@@ -392,15 +403,25 @@ __device__ __forceinline__ void hit_always(const DScene& sc, V3 o, V3 d, const R
         if (COUNT) cn.rect++;
         if (i == from_rect) continue;
         ObjRay q;
+        float inv;
         if (r.axes >> 8) {                   // instance: a rotation keeps |d|, so t means the same
             q = to_object(sc.xforms[(r.axes >> 8) - 1], o, d, r.axes & 3, sc.rect_k[i]);
+            inv = polished_rcp(comp(q.d, r.axes & 3));
         } else {
+            inv = comp(inv_d, r.axes & 3);
             // the distance to the plane: in float when the plane coordinate is a float (the
             // subtraction is then as good as the double one rounded), else in double
             q.o = o; q.d = d;
             q.num = (r.axes & 64) ? (float)(sc.rect_k[i] - (double)comp(o, r.axes & 3)) : r.k - comp(o, r.axes & 3);
         }
-        if (rect_test(r, q.num, q.o, q.d, t_min, kInf, t)) {
+        // the rect's axes are the same in every lane: one copy of the test per plane axis, each on the
+        // components themselves, instead of two selects per component picked by number
+        bool hit;
+        const int ka = __builtin_amdgcn_readfirstlane(r.axes & 3);
+        if (ka == 0) hit = rect_test<0>(r, q.num, inv, q.o, q.d, t_min, kInf, t);
+        else if (ka == 1) hit = rect_test<1>(r, q.num, inv, q.o, q.d, t_min, kInf, t);
+        else hit = rect_test<2>(r, q.num, inv, q.o, q.d, t_min, kInf, t);
+        if (hit) {
             float tn = t * rn.len;
             if (better(tn, r.obj, best)) { best.tn = tn; best.kind = 2; best.idx = i; best.obj = r.obj; }
         }
@@ -428,6 +449,8 @@ __device__ __forceinline__ void hit_list(const DScene& sc, const float4* staged,
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             float sx, sy, sz, sr;
+            // (the padding of a short list is not screened: a wave-uniform skip)
+            if (k >= 2 && i + k >= sc.n_sph) { tca[k] = 0.0f; gap[k] = -1.0f; continue; }
             if constexpr (STAGED) {
                 // from the workgroup's LDS copy: every lane reads the same address (a broadcast)
                 const float4 s4 = staged[i + k];
