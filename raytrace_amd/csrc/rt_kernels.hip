@@ -740,8 +740,10 @@ __device__ __forceinline__ Rec make_record(const DScene& sc, const Cand& c, V3 o
             if (ka == 0) r.p.x = q.k; else if (ka == 1) r.p.y = q.k; else r.p.z = q.k;      // q.k is k rounded to float
             face(r, d, axis);
         }
-        r.u = (comp(po, aa) - q.a0) / (q.a1 - q.a0);
-        r.v = (comp(po, ba) - q.b0) / (q.b1 - q.b0);
+        if (want_uv) {                         // cuda/rect.h:45-46; only a textured material looks at them
+            r.u = (comp(po, aa) - q.a0) / (q.a1 - q.a0);
+            r.v = (comp(po, ba) - q.b0) / (q.b1 - q.b0);
+        }
         r.mat = q.mat;
         return r;
     }
