@@ -495,7 +495,7 @@ int rt_upload_scene(rt_context* ctx, const rt_scene_desc* d) {
             // build over the uploaded (input order) spheres, then permute the arrays into leaf
             // order; the second set of arrays starts as a copy so that it carries the padding
             rt::LbvhResult lb;
-            hipError_t e = rt::build_lbvh(s.sph64, (int)ns, ctx->stream, &lb);
+            hipError_t e = rt::build_lbvh(s.sph64, (int)ns, ns > 65536 ? 2 : 4, ctx->stream, &lb);   // small leaves for large scenes, as the host builder
             const float4* sph2 = nullptr; const double4* sph642 = nullptr; const int2* info2 = nullptr; const int* xf2 = nullptr;
             if (e == hipSuccess) {
                 ctx->scene_allocs.push_back(lb.nodes);

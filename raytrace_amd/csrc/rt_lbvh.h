@@ -17,9 +17,10 @@ struct LbvhResult {
     int depth = 0;              // inner levels on the longest root-to-leaf path
 };
 
-// sph64: n spheres (cx, cy, cz, r) in input order, device memory; n > 4.  Synchronises `stream`
-// twice (node count, depth).  On failure nothing is left allocated.
-hipError_t build_lbvh(const double4* sph64, int n, hipStream_t stream, LbvhResult* out);
+// sph64: n spheres (cx, cy, cz, r) in input order, device memory; n > 4.  Subtrees of at most
+// leaf_max (1 .. 4) spheres become leaves.  Synchronises `stream` twice (node count, depth).  On
+// failure nothing is left allocated.
+hipError_t build_lbvh(const double4* sph64, int n, int leaf_max, hipStream_t stream, LbvhResult* out);
 
 // Leaf-order copies of the per-sphere arrays: dst[k] = src[order[k]] for k < n.  Entries
 // n .. n_padded-1 of the destinations must have been filled by the caller.

@@ -6,7 +6,7 @@
 //   hierarchy   binary radix tree over the sorted keys: node i owns a contiguous range of the
 //               sorted spheres and splits it where the keys' common prefix ends (one thread
 //               per inner node, no dependence between nodes)
-//   collapse    subtrees of <= 4 spheres become leaves; the surviving inner nodes are
+//   collapse    subtrees of <= leaf_max spheres become leaves; the surviving inner nodes are
 //               renumbered by a prefix sum
 //   fit         boxes bottom-up: the second thread to arrive at a node owns it and goes on
 //   assemble    64-byte nodes holding both children's boxes (layout: rt_device.h)
@@ -167,14 +167,14 @@ __global__ __launch_bounds__(kThreads) void hierarchy_kernel(const unsigned long
     if (i == 0) parent[0] = -1;
 }
 
-__global__ __launch_bounds__(kThreads) void kept_kernel(const int2* __restrict__ range, int n, int* __restrict__ kept) {
+__global__ __launch_bounds__(kThreads) void kept_kernel(const int2* __restrict__ range, int n, int leaf_max, int* __restrict__ kept) {
     int i = blockIdx.x * kThreads + threadIdx.x;
     if (i >= n - 1) return;
     int2 r = range[i];
-    kept[i] = (r.y - r.x + 1) > kLeafMax ? 1 : 0;
+    kept[i] = (r.y - r.x + 1) > leaf_max ? 1 : 0;
 }
 
-// Boxes and heights bottom-up.  A thread starts at every subtree that becomes a leaf (<= 4
+// Boxes and heights bottom-up.  A thread starts at every subtree that becomes a leaf (<= leaf_max
 // spheres under a parent that holds more) and climbs; at each inner node the first of its two
 // arrivals stops and the second, which finds the sibling's result published, goes on.  Every
 // thread stops at the latest at the root.  Results of other threads are read with agent-scope
@@ -182,16 +182,16 @@ __global__ __launch_bounds__(kThreads) void kept_kernel(const int2* __restrict__
 __global__ __launch_bounds__(kThreads) void fit_kernel(const double4* __restrict__ sph, const int* __restrict__ vals, int n,
                                                       const int2* __restrict__ child, const int2* __restrict__ range,
                                                       const int* __restrict__ parent, unsigned* __restrict__ kbox,
-                                                      int* __restrict__ height, int* __restrict__ arrivals, int* __restrict__ depth_out) {
+                                                      int* __restrict__ height, int* __restrict__ arrivals, int* __restrict__ depth_out, int leaf_max) {
     int u = blockIdx.x * kThreads + threadIdx.x;
     if (u >= 2 * n - 1) return;
     int first, count;
     if (u < n - 1) { int2 r = range[u]; first = r.x; count = r.y - r.x + 1; }
     else { first = u - (n - 1); count = 1; }
-    if (count > kLeafMax) return;
+    if (count > leaf_max) return;
     int p = parent[u];
     if (p < 0) return;                                    // cannot happen for n > 4: the root holds more than 4
-    { int2 r = range[p]; if (r.y - r.x + 1 <= kLeafMax) return; }   // inside a subtree that is collapsed higher up
+    { int2 r = range[p]; if (r.y - r.x + 1 <= leaf_max) return; }   // inside a subtree that is collapsed higher up
 
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (int k = first; k < first + count; k++) {
@@ -289,9 +289,9 @@ inline int blocks(long long n) { return (int)((n + kThreads - 1) / kThreads); }
 
 #define LB(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return e_; } while (0)
 
-hipError_t build_lbvh(const double4* sph64, int n, hipStream_t stream, LbvhResult* out) {
+hipError_t build_lbvh(const double4* sph64, int n, int leaf_max, hipStream_t stream, LbvhResult* out) {
     *out = LbvhResult{};
-    if (n <= kLeafMax || n > (1 << 28)) return hipErrorInvalidValue;
+    if (leaf_max < 1 || leaf_max > kLeafMax || n <= kLeafMax || n > (1 << 28)) return hipErrorInvalidValue;
     Scratch mem;
     unsigned* lohi; unsigned long long *keys, *keys_sorted; int *vals, *vals_sorted;
     int2 *child, *range; int *parent, *kept, *newidx, *arrivals, *height, *depth_dev; unsigned* kbox;
@@ -315,13 +315,13 @@ hipError_t build_lbvh(const double4* sph64, int n, hipStream_t stream, LbvhResul
     LB(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys_sorted, vals, vals_sorted, (size_t)n, 0u, 63u, stream));
 
     hipLaunchKernelGGL(hierarchy_kernel, dim3(blocks(n - 1)), dim3(kThreads), 0, stream, keys_sorted, n, child, range, parent);
-    hipLaunchKernelGGL(kept_kernel, dim3(blocks(n - 1)), dim3(kThreads), 0, stream, range, n, kept);
+    hipLaunchKernelGGL(kept_kernel, dim3(blocks(n - 1)), dim3(kThreads), 0, stream, range, n, leaf_max, kept);
     LB(hipGetLastError());
     LB(rocprim::exclusive_scan(tmp, scan_bytes, kept, newidx, 0, (size_t)(n - 1), rocprim::plus<int>(), stream));
     LB(hipMemsetAsync(arrivals, 0, (size_t)(n - 1) * sizeof(int), stream));
     LB(hipMemsetAsync(depth_dev, 0, sizeof(int), stream));
     hipLaunchKernelGGL(fit_kernel, dim3(blocks(2 * (long long)n - 1)), dim3(kThreads), 0, stream, sph64, vals_sorted, n, child, range,
-                       parent, kbox, height, arrivals, depth_dev);
+                       parent, kbox, height, arrivals, depth_dev, leaf_max);
     LB(hipGetLastError());
 
     int last_kept = 0, last_idx = 0, depth = 0;
