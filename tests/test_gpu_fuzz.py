@@ -178,6 +178,14 @@ def test_random_sphere_field(seed, oracle):
     for _ in range(1000):
         o = offset + rng.uniform(-0.5, 0.5, 3) * side * scale * [1, 0.2, 1] + [0, 0.12 * side * scale, 0]
         rays.append(np.concatenate([o, _unit(rng.normal(size=3)) * rng.uniform(0.3, 2)]))
+    # rays along an axis, in an axis plane, and a hair off either: the slab test's special cases
+    # (a reciprocal of +-1e30, per-axis rounding margins that grow with |o/d|)
+    for k in range(600):
+        o = offset + rng.uniform(-0.5, 0.5, 3) * side * scale * [1, 0.2, 1] + [0, 0.12 * side * scale, 0]
+        dvec = _unit(rng.normal(size=3)) * rng.uniform(0.3, 2)
+        zero = rng.choice(3, size=int(rng.integers(1, 3)), replace=False)
+        dvec[zero] = 0.0 if k % 2 == 0 else rng.choice([-1, 1], size=len(zero)) * 10.0 ** rng.uniform(-12, -5, size=len(zero))
+        rays.append(np.concatenate([o, dvec]))
     rays = np.asarray(rays, np.float64).astype(np.float32).astype(np.float64)
     want = oracle.trace(flat, rays, t_min=0.001)
     W, H, spp, depth = 60, 40, 4, int(rng.choice([3, 50]))
