@@ -184,8 +184,10 @@ int rt_render(rt_context* ctx, const rt_render_params* params, float* rgba_devic
 /* Same into HOST memory; returns when the image is there. */
 int rt_render_host(rt_context* ctx, const rt_render_params* params, float* rgba_host);
 
-/* Closest hit of n explicit rays (host arrays; rays = n x (ox oy oz dx dy dz)).  The device copies of
- * rays and hits live in a buffer the context keeps, and grows when n exceeds every earlier n. */
+/* Closest hit of n explicit rays (host arrays; rays = n x (ox oy oz dx dy dz)).  A tree is walked as a
+ * frame walks one that does not fit in LDS: through its 32-byte nodes where the scene has them
+ * (rt_stats.bvh_coarse_nodes == 0), else through the 64-byte ones.  The device copies of rays and hits live
+ * in a buffer the context keeps, and grows when n exceeds every earlier n. */
 int rt_trace_primary(rt_context* ctx, const float* rays_host, int32_t n, float t_min, rt_hit* hits_host);
 
 /* rt_trace_primary for callers that cannot allocate device memory: tight serving loops, harnesses that

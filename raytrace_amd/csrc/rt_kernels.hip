@@ -655,21 +655,6 @@ __device__ __forceinline__ void hit_bvh(const G& geo, V3 o, const RayN& rn, Orig
     if constexpr (SLICED) sp = (int)((top - bottom) / kStackStride);
 }
 
-// Closest hit over the whole scene.
-template <bool COUNT>
-__device__ __forceinline__ Cand closest_hit(const DScene& sc, V3 o, V3 d, float t_min, int* stack, Counters& cn) {
-    Cand best = no_hit();
-    RayN rn = normalise(d, t_min);
-    hit_always<COUNT, true>(sc, o, d, rn, t_min, no_origin(), best, cn);
-    GeoGlobal geo = {sc.nodes, sc.sph, sc.sph_info, mk(sc.tree_reach[0], sc.tree_reach[1], sc.tree_reach[2])};
-    if (!sc.use_bvh) hit_list<COUNT, false>(sc, nullptr, o, rn, no_origin(), best, cn);
-    else if (sc.root != kNoBvh) {
-        int cur = sc.root, sp = 0;
-        hit_bvh<COUNT, false>(geo, o, rn, no_origin(), stack, 0, 0, cur, sp, best, cn);
-    }
-    return best;
-}
-
 // ---- hit record ------------------------------------------------------------------------------
 
 struct Rec {
@@ -1295,6 +1280,24 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? RT_WG_PER_CU_SCAN : RT_WG_PER_C
 
 // ---- closest-hit kernel for explicit rays (parity hook) ------------------------------------------------------------------
 
+// Closest hit over the whole scene (QUANT: a tree is walked through its 32-byte nodes, as a frame
+// walks a tree that does not fit in LDS).
+template <bool COUNT, bool QUANT>
+__device__ __forceinline__ Cand closest_hit(const DScene& sc, V3 o, V3 d, float t_min, int* stack, Counters& cn) {
+    Cand best = no_hit();
+    RayN rn = normalise(d, t_min);
+    hit_always<COUNT, true>(sc, o, d, rn, t_min, no_origin(), best, cn);
+    const auto geo = stage_geometry<false, QUANT>(sc, nullptr);
+    if (!sc.use_bvh) hit_list<COUNT, false>(sc, nullptr, o, rn, no_origin(), best, cn);
+    else if (sc.root != kNoBvh) {
+        int cur = sc.root, sp = 0;
+        hit_bvh<COUNT, false>(geo, o, rn, no_origin(), stack, 0, 0, cur, sp, best, cn);
+    }
+    return best;
+}
+
+
+template <bool QUANT>
 __global__ __launch_bounds__(kBlock) void trace_kernel(DScene sc, const float* __restrict__ rays, int n, float t_min,
                                                        uint32_t flags, Hit* __restrict__ out) {
     __shared__ int s_stack[kMaxStack * kBlock];
@@ -1304,7 +1307,7 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(DScene sc, const float* _
     V3 o = mk(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]);
     V3 d = mk(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]);
     Counters cn = {0, 0, 0, 0, 0, 0, 0, 0};
-    Cand c = closest_hit<false>(sc, o, d, t_min, stack, cn);
+    Cand c = closest_hit<false, QUANT>(sc, o, d, t_min, stack, cn);
     Hit h;
     if (c.kind < 0) {
         h.id = -1; h.t = 0.0f; h.front = 0; h.u = 0.0f; h.v = 0.0f;
@@ -1429,7 +1432,11 @@ hipError_t launch_render(const DScene& sc, const DCamera& cam, const DRender& rp
 hipError_t launch_trace(const DScene& sc, const float* rays, int n, float t_min, uint32_t flags, Hit* out,
                         hipStream_t stream) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(trace_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, sc, rays, n, t_min, flags, out);
+    // the walk a frame of this scene would use when the tree does not fit in LDS
+    if (sc.use_bvh && sc.qnodes != nullptr && (flags & 128u) == 0u)
+        hipLaunchKernelGGL(trace_kernel<true>, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, sc, rays, n, t_min, flags, out);
+    else
+        hipLaunchKernelGGL(trace_kernel<false>, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, sc, rays, n, t_min, flags, out);
     return hipGetLastError();
 }
 

@@ -117,7 +117,8 @@ def test_random_scene(seed, oracle):
         if accel != api.RT_ACCEL_LIST:
             # the same tree read from HBM instead of LDS, and walked in time slices (what scenes too
             # large for LDS and trees deeper than 12 levels get): the same frame, the same ray count
-            for flags, slice_steps in ((api.RT_FLAG_NO_LDS_SCENE, 0), (0, 3), (api.RT_FLAG_NO_LDS_SCENE, 5)):
+            for flags, slice_steps in ((api.RT_FLAG_NO_LDS_SCENE, 0), (0, 3), (api.RT_FLAG_NO_LDS_SCENE, 5),
+                                        (api.RT_FLAG_NO_LDS_SCENE | api.RT_FLAG_FLOAT_NODES, 0)):
                 other = ctx.render_host(api.Context.params(W, H, spp, 50, 77 + seed, flags=flags, traversal_slice=slice_steps))
                 assert np.array_equal(other, img), (accel, flags, slice_steps)
                 assert ctx.stats()["rays"] == st["rays"]
