@@ -21,6 +21,9 @@
 #ifndef RT_WG_PER_CU
 #define RT_WG_PER_CU 5                 // workgroups of 256 threads per CU = waves per SIMD the tree-walking kernels are compiled for
 #endif
+#ifndef RT_WG_PER_CU_HBM
+#define RT_WG_PER_CU_HBM 6             // the same for walks of a tree in HBM: more waves to wait on memory with
+#endif
 #ifndef RT_WG_PER_CU_SCAN
 #define RT_WG_PER_CU_SCAN 6            // the same for the linear-scan kernels (fewer live values: 6 measured 5 % faster than 5)
 #endif
@@ -1074,7 +1077,7 @@ __device__ __forceinline__ float from_fixed(unsigned long long q) { return (floa
 // own: code that a scene never runs (rects, the scan, the tree walk) still costs the code that
 // does run registers and scheduling freedom when it shares a kernel with it.
 template <bool COUNT, bool LDS, bool PROF, int MODE, bool RECTS, bool QUANT>
-__global__ __launch_bounds__(kBlock, MODE == 0 ? RT_WG_PER_CU_SCAN : RT_WG_PER_CU) void render_kernel(DScene sc, DCamera cam, DRender rp, float4* __restrict__ out,
+__global__ __launch_bounds__(kBlock, MODE == 0 ? RT_WG_PER_CU_SCAN : (LDS ? RT_WG_PER_CU : RT_WG_PER_CU_HBM)) void render_kernel(DScene sc, DCamera cam, DRender rp, float4* __restrict__ out,
                                                         unsigned long long* __restrict__ counters) {
     constexpr bool SLICED = MODE == 2, BVH = MODE != 0;
     extern __shared__ __align__(16) int s_dyn[];
@@ -1371,11 +1374,7 @@ hipError_t launch_render(const DScene& sc, const DCamera& cam, const DRender& rp
     const long long tiles = (long long)((rp.width + TW - 1) / TW) * ((rp.rows + TH - 1) / TH);
     if (tiles <= 0) return hipSuccess;
     if (tiles > 0x7fffffffLL) return hipErrorInvalidValue;
-    // persistent waves: enough workgroups to fill 256 CUs at the kernel's occupancy
-    // (5 workgroups per CU), never more than there are tiles
     long long blocks = (tiles + (kBlock / 64) - 1) / (kBlock / 64);
-    const int wg_per_cu = sc.use_bvh ? RT_WG_PER_CU : RT_WG_PER_CU_SCAN;
-    if (blocks > 256 * wg_per_cu) blocks = 256 * wg_per_cu;
     // dynamic LDS: the traversal stack (one entry per BVH level), the per-pixel accumulators and,
     // when it all fits in a budget that still leaves four workgroups per CU, a copy of the BVH
     // and the sphere list
@@ -1397,6 +1396,10 @@ hipError_t launch_render(const DScene& sc, const DCamera& cam, const DRender& rp
     r.stack_depth = (in_lds && sc.use_bvh) ? short_depth : entries;
     size_t lds = (size_t)r.stack_depth * kBlock * sizeof(int) + accum_bytes;
     if (in_lds) lds += geo_bytes;
+    // persistent waves: enough workgroups to fill 256 CUs at the kernel's occupancy, never more
+    // than there are tiles
+    const int wg_per_cu = sc.use_bvh ? (in_lds ? RT_WG_PER_CU : RT_WG_PER_CU_HBM) : RT_WG_PER_CU_SCAN;
+    if (blocks > 256 * wg_per_cu) blocks = 256 * wg_per_cu;
     const bool count = (rp.flags & 4u) != 0u;
     const bool prof = (rp.flags & 8u) != 0u;
     dim3 grid((unsigned)blocks), block(kBlock);
@@ -1406,7 +1409,9 @@ hipError_t launch_render(const DScene& sc, const DCamera& cam, const DRender& rp
     // on slabs of 2 x 10^4, 10^5 and 10^6 spheres, 15 / 17 / 21 levels: best at about 128, 64, 48
     // steps; against the 32 used before: -8 %, -7 %, -2 % of the frame).  The image does not depend on it.
     if (r.slice == 0x7fffffff) r.slice = sc.bvh_depth > 12 ? (sc.bvh_depth >= 20 ? 48 : (sc.bvh_depth >= 16 ? 64 : 128)) : 0;
-    if (r.leaf_quorum < 0) r.leaf_quorum = 2;
+    // (with six waves per SIMD on a tree in HBM the walkers may be a little fewer before the wave
+    // turns to its leaves: 10^6 spheres -2.5 % against a ratio of 2)
+    if (r.leaf_quorum < 0) r.leaf_quorum = in_lds ? 2 : 4;
 
     const bool sliced = sc.use_bvh && r.slice > 0;
 #define RT_LAUNCH(...) hipLaunchKernelGGL((render_kernel<__VA_ARGS__>), grid, block, lds, stream, sc, cam, r, out, counters)
