@@ -111,9 +111,6 @@ enum {
     RT_FLAG_NO_LDS_SCENE = 1u << 5, /* read BVH and spheres from HBM even when they would fit in LDS */
     RT_FLAG_FLOAT_NODES = 1u << 7, /* a tree read from HBM is walked through its 64-byte single-precision nodes
                                      instead of the 32-byte quantised ones (same image; for comparison) */
-    RT_FLAG_WIDE_NODES = 1u << 8, /* a tree read from HBM is walked through its four-wide 64-byte nodes (the same
-                                     16-bit planes, four children per node: half as many dependent fetches per ray)
-                                     where the scene has them; same image */
     RT_FLAG_FIXED_SUMS = 1u << 6  /* the image is written as the kernel accumulates it: per pixel four uint64_t
                                      (r, g, b sums of sample radiance in unsigned 32.32 fixed point, sample
                                      count), 32 bytes.  Integer sums of sample windows (sample_begin) add up
@@ -167,9 +164,6 @@ typedef struct rt_stats {
     int32_t bvh_coarse_nodes;    /* inner nodes whose boxes the 16-bit grid of the 32-byte nodes would blow up to more than
                                     twice their surface area; 0: a walk out of HBM reads the 32-byte nodes, else the
                                     64-byte ones */
-    int32_t bvh_wide_nodes;      /* four-wide nodes the quantised tree folds into (0: the scene has no such form) */
-    int32_t bvh_wide_depth;      /* their levels on the longest path */
-    int32_t bvh_wide_stack;      /* stack entries the worst walk through them holds at once */
 } rt_stats;
 
 int rt_create(int device, rt_context** out);

@@ -16,7 +16,6 @@ RT_ERR_INVALID, RT_ERR_NO_DEVICE, RT_ERR_HIP, RT_ERR_NO_SCENE, RT_ERR_NO_CAMERA,
 RT_ACCEL_AUTO, RT_ACCEL_LIST, RT_ACCEL_BVH, RT_ACCEL_BVH_DEVICE = 0, 1, 2, 3
 TRACE_NOALLOC_MAX_RAYS = 65536           # RT_TRACE_NOALLOC_MAX_RAYS
 RT_FLAG_MEAN, RT_FLAG_NO_REFINE, RT_FLAG_COUNTERS, RT_FLAG_PHASE_CLOCKS, RT_FLAG_NO_LDS_SCENE, RT_FLAG_FIXED_SUMS, RT_FLAG_FLOAT_NODES = 1, 2, 4, 8, 32, 64, 128
-RT_FLAG_WIDE_NODES = 256
 
 EXPORTS = ["rt_create", "rt_destroy", "rt_set_stream", "rt_upload_scene", "rt_set_camera",
            "rt_shard_rows", "rt_render", "rt_render_host", "rt_trace_primary", "rt_trace_primary_noalloc", "rt_quantize",
@@ -72,8 +71,7 @@ class Stats(C.Structure):
                 ("wide_tests", C.c_uint64), ("shades", C.c_uint64), ("phase_clocks", C.c_uint64 * 5),
                 ("kernel_ms", C.c_float),
                 ("lanes_per_pixel", C.c_int32), ("accel", C.c_int32), ("bvh_nodes", C.c_int32),
-                ("bvh_depth", C.c_int32), ("build_ms", C.c_float), ("bvh_coarse_nodes", C.c_int32),
-                ("bvh_wide_nodes", C.c_int32), ("bvh_wide_depth", C.c_int32), ("bvh_wide_stack", C.c_int32)]
+                ("bvh_depth", C.c_int32), ("build_ms", C.c_float), ("bvh_coarse_nodes", C.c_int32)]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_}

@@ -32,8 +32,6 @@ struct rt_context {
     int bvh_nodes = 0, bvh_depth = 0;
     float build_ms = 0.0f;
     int coarse_nodes = 0;          // nodes the 16-bit grid is too coarse for (any: the tree is walked in its float form)
-    int wide_nodes = 0, wide_depth = 0, wide_stack = 0;   // the four-wide form of the quantised tree, when the scene has one
-    int wide_stack_cap = 0;        // stack entries the fold may plan for (0: the traversal stack's size)
 
     // per-render state
     unsigned long long* counters = nullptr;   // device, rt::kNumCounters
@@ -549,25 +547,6 @@ int rt_upload_scene(rt_context* ctx, const rt_scene_desc* d) {
         // a grid too coarse for some node (fine detail in a wide scene): the tree keeps its float form
         if (ctx->coarse_nodes == 0) {
             s.qnodes = static_cast<const uint4*>(qn);
-            // Scenes too large for LDS: the same planes folded into four-wide nodes (host fold of the
-            // quantised nodes; the planes stay what they are, so the boxes hold what they held)
-            ctx->wide_nodes = ctx->wide_depth = ctx->wide_stack = 0;
-            if (ns > 1024 && n_nodes < (1 << 26)) {
-                std::vector<uint32_t> q2((size_t)n_nodes * 8);
-                RT_HIP(ctx, hipMemcpy(q2.data(), qn, q2.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
-                const int cap = ctx->wide_stack_cap > 0 ? std::min(ctx->wide_stack_cap, rt::kMaxStack - 2) : rt::kMaxStack - 2;
-                const int32_t empty_leaf = ~(int32_t)(((uint32_t)ns << rt::kLeafBits) | 0u);      // the first padding record: nothing can hit it
-                rt::Bvh4qResult w = rt::collapse_bvh4q(q2.data(), (size_t)n_nodes, root, empty_leaf, std::max(cap, depth));
-                if (w.root >= 0 && w.root != rt::kNoBvh && !w.nodes.empty() && w.stack_need <= rt::kMaxStack - 2) {
-                    std::vector<uint4> up(w.nodes.size() / 4);
-                    std::memcpy(up.data(), w.nodes.data(), w.nodes.size() * sizeof(uint32_t));
-                    const uint4* dev = nullptr;
-                    int rc = upload(ctx, up, &dev);
-                    if (rc) { std::string keep = ctx->error; free_scene(ctx); ctx->error = keep; return rc; }
-                    s.wnodes = dev; s.wide_root = w.root; s.wide_stack = w.stack_need; s.n_wnodes = (int)(w.nodes.size() / 16);
-                    ctx->wide_nodes = s.n_wnodes; ctx->wide_depth = w.depth; ctx->wide_stack = w.stack_need;
-                }
-            }
         } else {
             ctx->scene_allocs.pop_back();
             (void)hipFree(qn);
@@ -592,13 +571,6 @@ int rt_upload_scene(rt_context* ctx, const rt_scene_desc* d) {
     ctx->bvh_nodes = n_nodes;
     ctx->bvh_depth = depth;
     ctx->has_scene = true;
-    return RT_OK;
-}
-
-// experiment hook (not in rt.h): stack entries the four-wide fold of the next upload may plan for
-extern "C" int rt_tune_wide_stack(rt_context* ctx, int cap) {
-    if (!ctx) return RT_ERR_INVALID;
-    ctx->wide_stack_cap = cap;
     return RT_OK;
 }
 
@@ -733,7 +705,6 @@ int rt_get_stats(rt_context* ctx, rt_stats* out) {
     out->bvh_depth = ctx->bvh_depth;
     out->build_ms = ctx->build_ms;
     out->bvh_coarse_nodes = ctx->coarse_nodes;
-    out->bvh_wide_nodes = ctx->wide_nodes; out->bvh_wide_depth = ctx->wide_depth; out->bvh_wide_stack = ctx->wide_stack;
     return RT_OK;
 }
 

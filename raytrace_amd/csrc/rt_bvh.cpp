@@ -209,108 +209,4 @@ BvhResult build_bvh(const double* centers, const double* radii, int64_t n, int m
     return res;
 }
 
-namespace {
-
-// see collapse_bvh4q (rt_bvh.h)
-struct Collapser {
-    const uint32_t* nodes2;
-    std::vector<uint32_t> out;
-    std::vector<uint8_t> height;      // inner levels of the binary subtree below each binary node
-    int32_t empty_leaf = -1;
-    int depth = 0, stack_need = 0;
-    bool capped = false;
-
-    struct Child { int32_t ref; uint32_t plane[3]; };
-
-    void children_of(int32_t node2, Child& l, Child& r) const {
-        const uint32_t* q = nodes2 + 8 * (size_t)node2;
-        for (int a = 0; a < 3; a++) { l.plane[a] = q[a]; r.plane[a] = q[3 + a]; }
-        l.ref = (int32_t)q[6];
-        r.ref = (int32_t)q[7];
-    }
-    static double half_area(const Child& c) {
-        double e[3];
-        for (int a = 0; a < 3; a++) e[a] = (double)(c.plane[a] >> 16) - (double)(c.plane[a] & 0xffffu);
-        return e[0] * e[1] + e[1] * e[2] + e[2] * e[0];
-    }
-    int height_of(int32_t ref) const { return ref >= 0 ? height[(size_t)ref] : 0; }
-
-    int fill_heights(int32_t node2) {
-        Child l, r;
-        children_of(node2, l, r);
-        const int hl = l.ref >= 0 ? fill_heights(l.ref) : 0, hr = r.ref >= 0 ? fill_heights(r.ref) : 0;
-        const int h = 1 + std::max(hl, hr);
-        height[(size_t)node2] = (uint8_t)std::min(h, 255);
-        return h;
-    }
-
-    // emits the wide node that stands for binary node `node2`; returns its index.  `budget`: stack
-    // entries the walk may still use from here (at least the binary subtree's height, which is what
-    // a walk through two-wide nodes needs); `need`: entries the worst walk below actually uses.
-    int32_t emit(int32_t node2, int level, int budget, int* need) {
-        Child c[4];
-        int n = 2;
-        children_of(node2, c[0], c[1]);
-        while (n < 4) {
-            int pick = -1;
-            double area = -1.0;
-            for (int i = 0; i < n; i++)
-                if (c[i].ref >= 0 && half_area(c[i]) > area) { area = half_area(c[i]); pick = i; }
-            if (pick < 0) break;
-            if (capped) {
-                // one more child is one more entry for every path through this node
-                int tallest = height_of(c[pick].ref) - 1;
-                for (int i = 0; i < n; i++) if (i != pick) tallest = std::max(tallest, height_of(c[i].ref));
-                if (n + tallest > budget) break;
-            }
-            Child l, r;
-            children_of(c[pick].ref, l, r);
-            c[pick] = l;
-            c[n++] = r;
-        }
-        const int32_t me = (int32_t)(out.size() / 16);
-        out.resize(out.size() + 16);
-        depth = std::max(depth, level + 1);
-        int below = 0;
-        uint32_t refs[4];
-        for (int i = 0; i < 4; i++) {
-            if (i < n) {
-                int sub = 0;
-                refs[i] = (uint32_t)(c[i].ref >= 0 ? emit(c[i].ref, level + 1, budget - (n - 1), &sub) : c[i].ref);
-                below = std::max(below, sub);
-            } else {
-                refs[i] = (uint32_t)empty_leaf;
-                for (int a = 0; a < 3; a++) c[i].plane[a] = 0x0000ffffu;
-            }
-        }
-        uint32_t* q = out.data() + 16 * (size_t)me;            // (out may have grown: take the address now)
-        for (int i = 0; i < 4; i++)
-            for (int a = 0; a < 3; a++) q[3 * i + a] = c[i].plane[a];
-        for (int i = 0; i < 4; i++) q[12 + i] = refs[i];
-        *need = (n - 1) + below;
-        return me;
-    }
-};
-
-}  // namespace
-
-Bvh4qResult collapse_bvh4q(const uint32_t* qnodes2, size_t n_nodes2, int32_t root2, int32_t empty_leaf, int stack_cap) {
-    Bvh4qResult res;
-    res.root = root2;
-    if (root2 < 0 || root2 == 0x7fffffff || n_nodes2 == 0) return res;      // a leaf or nothing: no inner node to widen
-    Collapser c;
-    c.nodes2 = qnodes2;
-    c.empty_leaf = empty_leaf;
-    c.height.assign(n_nodes2, 0);
-    const int h = c.fill_heights(root2);
-    c.capped = stack_cap > 0;
-    c.out.reserve(n_nodes2 * 8);
-    int need = 0;
-    res.root = c.emit(root2, 0, std::max(stack_cap, h), &need);
-    res.depth = c.depth;
-    res.stack_need = need;
-    res.nodes = std::move(c.out);
-    return res;
-}
-
 }  // namespace rt

@@ -66,10 +66,6 @@ struct DScene {
                           // the arrays hold four more records, for leaves that are read four at a time
     const float4* nodes;
     const uint4* qnodes;  // the same nodes in 32 bytes (16-bit planes on the grid q_lo + k * q_step), or null when the grid is too coarse for some node: what frames walk out of HBM
-    const uint4* wnodes;  // the quantised nodes folded into four-wide 64-byte nodes (rt_bvh.h), or null
-    int wide_root;        // root of the four-wide tree (an inner index)
-    int wide_stack;       // most entries a walk of the four-wide tree holds on its stack at once
-    int n_wnodes;
     float q_lo[3], q_step[3];
     float tree_reach[3];  // largest |coordinate| of the tree's box planes, per axis (the slab test's rounding margins)
     int n_nodes;

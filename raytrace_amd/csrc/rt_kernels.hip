@@ -266,7 +266,6 @@ struct GeoGlobal {
     static constexpr bool kPrefetchLeaf = true;
     static constexpr bool kPlaneAddressed = false;
     static constexpr bool kQuant = false;
-    static constexpr bool kWide = false;
     const float4* nodes; const float4* sph; const int2* info;
     V3 reach;                                                    // largest |coordinate| of the tree's box planes, per axis
     __device__ __forceinline__ int root_ref(int root) const { return root; }
@@ -282,7 +281,6 @@ struct GeoGlobalQ {
     static constexpr bool kPrefetchLeaf = true;
     static constexpr bool kPlaneAddressed = false;
     static constexpr bool kQuant = true;
-    static constexpr bool kWide = false;
     const uint4* qnodes; const float4* sph; const int2* info;
     float lo[3], step[3];
     V3 reach;
@@ -291,26 +289,6 @@ struct GeoGlobalQ {
     // arithmetic; the quantised form is only made for trees of fewer than 2^27 nodes)
     __device__ __forceinline__ uint4 qnode(int i, int q) const {
         return *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(qnodes) + (((unsigned)i << 5) + 16u * q));
-    }
-    __device__ __forceinline__ float4 sphere(int i) const { return sph[i]; }
-    __device__ __forceinline__ int obj(int i) const { return info[i].x; }
-    __device__ __forceinline__ int mat(int i) const { return info[i].y; }
-};
-// The same tree folded into four-wide 64-byte nodes (rt_bvh.h, collapse_bvh4q): the planes of up to four
-// children on the same 16-bit grid, then their four codes.  A ray fetches half as many nodes one after
-// the other; the lookups per ray stay what they were (four 16-byte loads per two levels).
-struct GeoGlobalQ4 {
-    static constexpr bool kPrefetchLeaf = true;
-    static constexpr bool kPlaneAddressed = false;
-    static constexpr bool kQuant = true;
-    static constexpr bool kWide = true;
-    const uint4* wnodes; const float4* sph; const int2* info;
-    float lo[3], step[3];
-    V3 reach;
-    int wroot;
-    __device__ __forceinline__ int root_ref(int) const { return wroot; }
-    __device__ __forceinline__ uint4 wnode(int i, int q) const {      // (trees of fewer than 2^26 wide nodes)
-        return *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(wnodes) + (((unsigned)i << 6) + 16u * q));
     }
     __device__ __forceinline__ float4 sphere(int i) const { return sph[i]; }
     __device__ __forceinline__ int obj(int i) const { return info[i].x; }
@@ -333,7 +311,6 @@ struct GeoLds {
     static constexpr bool kPrefetchLeaf = false;
     static constexpr bool kPlaneAddressed = true;
     static constexpr bool kQuant = false;
-    static constexpr bool kWide = false;
     unsigned node_base;                                          // LDS byte address of node 0
     const float4* sph; const int* objs;                          // both point into LDS
     V3 reach;
@@ -554,13 +531,6 @@ __device__ __forceinline__ int pop_ref(unsigned top) {
     if constexpr (SHORT) return (int)*(lds_short*)(size_t)top; else return *(lds_int*)(size_t)top;
 }
 
-// (distance, code) pairs in ascending distance
-__device__ __forceinline__ void order2(float& ta, int& ra, float& tb, int& rb) {
-    const bool swap = tb < ta;
-    const float t = swap ? tb : ta; tb = swap ? ta : tb; ta = t;
-    const int r = swap ? rb : ra; rb = swap ? ra : rb; ra = r;
-}
-
 template <bool COUNT, bool SLICED, class G>
 __device__ __forceinline__ void hit_bvh(const G& geo, V3 o, const RayN& rn, Origin from, int* stack, int budget, int quorum,
                                         int& cur, int& sp, Cand& best, Counters& cn) {
@@ -612,36 +582,6 @@ __device__ __forceinline__ void hit_bvh(const G& geo, V3 o, const RayN& rn, Orig
         bool leave = false;
         while (cur >= 0 && !stop && !leave) {
             if (COUNT) { cn.steps++; if (first_active_lane()) cn.wave_steps++; }
-            if constexpr (G::kWide) {
-                // four-wide node: the children that are met, in ascending entry distance (five
-                // compare-exchanges, a child that is not met counting as infinitely far); the nearest
-                // is taken next, the others are pushed farthest first
-                if (COUNT) cn.box += 4;
-                const uint4 a = geo.wnode(cur, 0), b = geo.wnode(cur, 1), c = geo.wnode(cur, 2), rf = geo.wnode(cur, 3);
-                auto child = [&](unsigned wx, unsigned wy, unsigned wz, float& t) -> bool {
-                    const unsigned x = __builtin_amdgcn_alignbit(wx, wx, sh_x), y = __builtin_amdgcn_alignbit(wy, wy, sh_y),
-                                   z = __builtin_amdgcn_alignbit(wz, wz, sh_z);
-                    return box_planes(half_lo(x), half_lo(y), half_lo(z), half_hi(x), half_hi(y), half_hi(z), qa, qb_in, qb_out, tn_min, best.tn, t);
-                };
-                float t0, t1, t2, t3;
-                const bool h0 = child(a.x, a.y, a.z, t0), h1 = child(a.w, b.x, b.y, t1), h2 = child(b.z, b.w, c.x, t2), h3 = child(c.y, c.z, c.w, t3);
-                int r0 = (int)rf.x, r1 = (int)rf.y, r2 = (int)rf.z, r3 = (int)rf.w;
-                t0 = h0 ? t0 : kInf; t1 = h1 ? t1 : kInf; t2 = h2 ? t2 : kInf; t3 = h3 ? t3 : kInf;
-                order2(t0, r0, t1, r1); order2(t2, r2, t3, r3);
-                order2(t0, r0, t2, r2); order2(t1, r1, t3, r3);
-                order2(t1, r1, t2, r2);
-                if (t3 < kInf) { push_ref<false>(top, r3); top += kStackStride; }
-                if (t2 < kInf) { push_ref<false>(top, r2); top += kStackStride; }
-                if (t1 < kInf) { push_ref<false>(top, r1); top += kStackStride; }
-                if (t0 < kInf) {
-                    cur = r0;
-                } else if (top != bottom) {
-                    top -= kStackStride;
-                    cur = pop_ref<false>(top);
-                } else {
-                    cur = kTravDone;
-                }
-            } else {
             int left, right;
             float tl, tr;
             bool hl, hr;
@@ -690,7 +630,6 @@ __device__ __forceinline__ void hit_bvh(const G& geo, V3 o, const RayN& rn, Orig
                 cur = pop_ref<G::kPlaneAddressed>(top);
             } else {
                 cur = kTravDone;
-            }
             }
             if constexpr (SLICED) {
                 waiting += __popcll(__ballot(cur < 0 && cur != kTravDone));
@@ -1074,18 +1013,15 @@ __device__ __forceinline__ bool shade(const DScene& sc, const G& geo, const DRen
     return !cont || depth >= rp.max_depth;             // main.cc:13-14: the limit ends in black
 }
 
-// QUANT: 0 single-precision nodes, 1 the 32-byte quantised nodes, 2 the four-wide 64-byte quantised nodes
-template <bool LDS, int QUANT>
+template <bool LDS, bool QUANT>
 struct GeoOf { using type = GeoGlobal; };
 template <>
-struct GeoOf<false, 1> { using type = GeoGlobalQ; };
-template <>
-struct GeoOf<false, 2> { using type = GeoGlobalQ4; };
-template <int QUANT>
+struct GeoOf<false, true> { using type = GeoGlobalQ; };
+template <bool QUANT>
 struct GeoOf<true, QUANT> { using type = GeoLds; };
 
 // Copies the BVH and the sphere list into LDS (LDS variant) behind `lds`.
-template <bool LDS, int QUANT>
+template <bool LDS, bool QUANT>
 __device__ __forceinline__ typename GeoOf<LDS, QUANT>::type stage_geometry(const DScene& sc, int* lds) {
     if constexpr (LDS) {
         float* nodes = reinterpret_cast<float*>(lds);
@@ -1107,10 +1043,7 @@ __device__ __forceinline__ typename GeoOf<LDS, QUANT>::type stage_geometry(const
         for (int i = sc.n_sph + threadIdx.x; i < sc.n_sph_padded; i += kBlock) { sph[i] = sc.sph[i]; objs[i] = 0; }   // the scan's padding
         GeoLds g = {base, sph, objs, mk(sc.tree_reach[0], sc.tree_reach[1], sc.tree_reach[2])};
         return g;
-    } else if constexpr (QUANT == 2) {
-        GeoGlobalQ4 g = {sc.wnodes, sc.sph, sc.sph_info, {sc.q_lo[0], sc.q_lo[1], sc.q_lo[2]}, {sc.q_step[0], sc.q_step[1], sc.q_step[2]}, mk(sc.tree_reach[0], sc.tree_reach[1], sc.tree_reach[2]), sc.wide_root};
-        return g;
-    } else if constexpr (QUANT == 1) {
+    } else if constexpr (QUANT) {
         GeoGlobalQ g = {sc.qnodes, sc.sph, sc.sph_info, {sc.q_lo[0], sc.q_lo[1], sc.q_lo[2]}, {sc.q_step[0], sc.q_step[1], sc.q_step[2]}, mk(sc.tree_reach[0], sc.tree_reach[1], sc.tree_reach[2])};
         return g;
     } else {
@@ -1143,7 +1076,7 @@ __device__ __forceinline__ float from_fixed(unsigned long long q) { return (floa
 // MODE: 0 linear scan, 1 BVH, 2 BVH walked in time slices.  Each combination is a kernel of its
 // own: code that a scene never runs (rects, the scan, the tree walk) still costs the code that
 // does run registers and scheduling freedom when it shares a kernel with it.
-template <bool COUNT, bool LDS, bool PROF, int MODE, bool RECTS, int QUANT>
+template <bool COUNT, bool LDS, bool PROF, int MODE, bool RECTS, bool QUANT>
 __global__ __launch_bounds__(kBlock, MODE == 0 ? RT_WG_PER_CU_SCAN : (LDS ? RT_WG_PER_CU : RT_WG_PER_CU_HBM)) void render_kernel(DScene sc, DCamera cam, DRender rp, float4* __restrict__ out,
                                                         unsigned long long* __restrict__ counters) {
     constexpr bool SLICED = MODE == 2, BVH = MODE != 0;
@@ -1352,7 +1285,7 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? RT_WG_PER_CU_SCAN : (LDS ? RT_W
 
 // Closest hit over the whole scene (QUANT: a tree is walked through its 32-byte nodes, as a frame
 // walks a tree that does not fit in LDS).
-template <bool COUNT, int QUANT>
+template <bool COUNT, bool QUANT>
 __device__ __forceinline__ Cand closest_hit(const DScene& sc, V3 o, V3 d, float t_min, int* stack, Counters& cn) {
     Cand best = no_hit();
     RayN rn = normalise(d, t_min);
@@ -1360,14 +1293,14 @@ __device__ __forceinline__ Cand closest_hit(const DScene& sc, V3 o, V3 d, float 
     const auto geo = stage_geometry<false, QUANT>(sc, nullptr);
     if (!sc.use_bvh) hit_list<COUNT, false>(sc, nullptr, o, rn, no_origin(), best, cn);
     else if (sc.root != kNoBvh) {
-        int cur = geo.root_ref(sc.root), sp = 0;
+        int cur = sc.root, sp = 0;
         hit_bvh<COUNT, false>(geo, o, rn, no_origin(), stack, 0, 0, cur, sp, best, cn);
     }
     return best;
 }
 
 
-template <int QUANT>
+template <bool QUANT>
 __global__ __launch_bounds__(kBlock) void trace_kernel(DScene sc, const float* __restrict__ rays, int n, float t_min,
                                                        uint32_t flags, Hit* __restrict__ out) {
     __shared__ int s_stack[kMaxStack * kBlock];
@@ -1460,10 +1393,7 @@ hipError_t launch_render(const DScene& sc, const DCamera& cam, const DRender& rp
                         sc.ids_fit_16 &&                  // the LDS copy packs list position and material into one word
                         (sc.use_bvh ? sc.n_sph_padded + 8 < 4096 && (size_t)short_depth * kBlock * sizeof(int) + accum_bytes + geo_bytes <= 40 * 1024
                                     : sc.n_sph_padded <= 32);
-    // a tree read from HBM may be walked through its four-wide nodes, which push up to three entries
-    // per level: the fold reports what the worst walk needs
-    const bool wide = sc.use_bvh && !in_lds && sc.qnodes != nullptr && sc.wnodes != nullptr && (rp.flags & 256u) != 0u && (rp.flags & 128u) == 0u;
-    r.stack_depth = (in_lds && sc.use_bvh) ? short_depth : (wide ? sc.wide_stack + 1 : entries);
+    r.stack_depth = (in_lds && sc.use_bvh) ? short_depth : entries;
     size_t lds = (size_t)r.stack_depth * kBlock * sizeof(int) + accum_bytes;
     if (in_lds) lds += geo_bytes;
     // persistent waves: enough workgroups to fill 256 CUs at the kernel's occupancy, never more
@@ -1487,8 +1417,7 @@ hipError_t launch_render(const DScene& sc, const DCamera& cam, const DRender& rp
 #define RT_LAUNCH(...) hipLaunchKernelGGL((render_kernel<__VA_ARGS__>), grid, block, lds, stream, sc, cam, r, out, counters)
     // a tree read from HBM is walked through its 32-byte quantised nodes
     const bool quant = sc.use_bvh && !in_lds && sc.qnodes != nullptr && (rp.flags & 128u) == 0u;
-#define RT_LAUNCH_Q(C, L, P, M, R) do { if (!L && M != 0 && quant && wide) RT_LAUNCH(C, L, P, M, R, ((!L && M != 0) ? 2 : 0)); \
-        else if (!L && M != 0 && quant) RT_LAUNCH(C, L, P, M, R, ((!L && M != 0) ? 1 : 0)); else RT_LAUNCH(C, L, P, M, R, 0); } while (0)
+#define RT_LAUNCH_Q(C, L, P, M, R) do { if (!L && M != 0 && quant) RT_LAUNCH(C, L, P, M, R, (!L && M != 0)); else RT_LAUNCH(C, L, P, M, R, false); } while (0)
 #define RT_LAUNCH_R(C, L, P, M) do { if (sc.n_rects > 0 || sc.has_textures) RT_LAUNCH_Q(C, L, P, M, true); else RT_LAUNCH_Q(C, L, P, M, false); } while (0)
 #define RT_LAUNCH_M(C, P) do { \
         if (!sc.use_bvh) { if (in_lds) RT_LAUNCH_R(C, true, P, 0); else RT_LAUNCH_R(C, false, P, 0); } \
@@ -1509,12 +1438,10 @@ hipError_t launch_trace(const DScene& sc, const float* rays, int n, float t_min,
                         hipStream_t stream) {
     if (n <= 0) return hipSuccess;
     // the walk a frame of this scene would use when the tree does not fit in LDS
-    if (sc.use_bvh && sc.qnodes != nullptr && sc.wnodes != nullptr && (flags & 128u) == 0u && (flags & 256u) != 0u)
-        hipLaunchKernelGGL(trace_kernel<2>, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, sc, rays, n, t_min, flags, out);
-    else if (sc.use_bvh && sc.qnodes != nullptr && (flags & 128u) == 0u)
-        hipLaunchKernelGGL(trace_kernel<1>, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, sc, rays, n, t_min, flags, out);
+    if (sc.use_bvh && sc.qnodes != nullptr && (flags & 128u) == 0u)
+        hipLaunchKernelGGL(trace_kernel<true>, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, sc, rays, n, t_min, flags, out);
     else
-        hipLaunchKernelGGL(trace_kernel<0>, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, sc, rays, n, t_min, flags, out);
+        hipLaunchKernelGGL(trace_kernel<false>, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, sc, rays, n, t_min, flags, out);
     return hipGetLastError();
 }
 
