@@ -260,12 +260,21 @@ __device__ __forceinline__ SlabRay slab_ray(V3 o, V3 dh, V3 reach) {
     return r;
 }
 
+// "Traversal finished" as a node reference.  Not a leaf code: a leaf code is ~(first << kLeafBits |
+// count - 1) over fewer than 2^28 spheres (rt_upload_scene's limit), so it stays above -2^31; with
+// the tree in LDS references are 16 bits wide and leaf codes range over fewer than 4088 sphere slots,
+// so they stay above -32768.  The entry below a lane's traversal stack holds this value: a walk pops
+// without asking whether anything is left, and what comes off an empty stack ends it.
+constexpr int kTravDone = (int)0x80000000;
+constexpr int kTravDone16 = -32768;
+
 // Where the traversal reads its geometry from: HBM (through L1/L2), or a copy in LDS that the
 // workgroup makes at kernel start when the whole BVH and sphere list fit.
 struct GeoGlobal {
     static constexpr bool kPrefetchLeaf = true;
     static constexpr bool kPlaneAddressed = false;
     static constexpr bool kQuant = false;
+    static constexpr int kDone = kTravDone;
     const float4* nodes; const float4* sph; const int2* info;
     V3 reach;                                                    // largest |coordinate| of the tree's box planes, per axis
     __device__ __forceinline__ int root_ref(int root) const { return root; }
@@ -281,6 +290,7 @@ struct GeoGlobalQ {
     static constexpr bool kPrefetchLeaf = true;
     static constexpr bool kPlaneAddressed = false;
     static constexpr bool kQuant = true;
+    static constexpr int kDone = kTravDone;
     const uint4* qnodes; const float4* sph; const int2* info;
     float lo[3], step[3];
     V3 reach;
@@ -311,6 +321,7 @@ struct GeoLds {
     static constexpr bool kPrefetchLeaf = false;
     static constexpr bool kPlaneAddressed = true;
     static constexpr bool kQuant = false;
+    static constexpr int kDone = kTravDone16;                     // what the 16-bit stack's bottom entry reads as
     unsigned node_base;                                          // LDS byte address of node 0
     const float4* sph; const int* objs;                          // both point into LDS
     V3 reach;
@@ -516,10 +527,8 @@ __device__ __forceinline__ void hit_own_sphere(const G& geo, V3 o, const RayN& r
 //
 // The traversal is resumable: (cur, sp) and `best` are its whole state.  With budget > 0 the
 // wave leaves after about that many node steps; lanes whose traversal is not finished
-// (cur != kTravDone) come back later with the same state, so one long ray does not hold the
+// (cur != G::kDone) come back later with the same state, so one long ray does not hold the
 // other 63 lanes of the wave.
-constexpr int kTravDone = (int)0x80000000;     // not a leaf code: ~kTravDone >> kLeafBits = 2^28 - 1 with count 8, and a leaf
-                                               // holds at most four spheres of at most 2^28 (rt_upload_scene's limit)
 
 typedef short __attribute__((address_space(3))) lds_short;
 template <bool SHORT>
@@ -566,12 +575,15 @@ __device__ __forceinline__ void hit_bvh(const G& geo, V3 o, const RayN& rn, Orig
     // the tree in LDS a reference fits 16 bits (a node's address in units of 16 bytes, or a leaf
     // code over fewer than 4096 sphere slots): half the stack, which is what lets the 80-byte nodes
     // in beside it at five workgroups per CU.
+    // Entry 0 of a lane's column holds G::kDone for the whole launch (render_kernel and trace_kernel
+    // write it): popping it ends the walk, so no pop asks whether the stack is empty.
     constexpr unsigned kStackStride = kBlock * (G::kPlaneAddressed ? sizeof(short) : sizeof(int));
-    const unsigned bottom = (unsigned)(size_t)(__attribute__((address_space(3))) char*)stack;
+    constexpr int kDone = G::kDone;
+    const unsigned bottom = (unsigned)(size_t)(__attribute__((address_space(3))) char*)stack + kStackStride;
     unsigned top = bottom + (unsigned)sp * kStackStride;
     int wave_steps = 0;
     bool stop = false;
-    while (cur != kTravDone && !stop) {
+    while (cur != kDone && !stop) {
         // Deep trees: a lane meets a leaf every seven or eight node steps, and waiting until all 64
         // lanes stand on one leaves most of them idle for most of the walk.  The wave therefore
         // turns to the leaves as soon as the lanes waiting at one, times `quorum`, outnumber the
@@ -625,14 +637,12 @@ __device__ __forceinline__ void hit_bvh(const G& geo, V3 o, const RayN& rn, Orig
                 cur = left_first ? left : right;
             } else if (hl || hr) {
                 cur = hl ? left : right;
-            } else if (top != bottom) {
+            } else {
                 top -= kStackStride;
                 cur = pop_ref<G::kPlaneAddressed>(top);
-            } else {
-                cur = kTravDone;
             }
             if constexpr (SLICED) {
-                waiting += __popcll(__ballot(cur < 0 && cur != kTravDone));
+                waiting += __popcll(__ballot(cur < 0 && cur != kDone));
                 leave = waiting * quorum >= __popcll(__ballot(cur >= 0));
             }
             if constexpr (SLICED) {
@@ -643,19 +653,16 @@ __device__ __forceinline__ void hit_bvh(const G& geo, V3 o, const RayN& rn, Orig
                 stop = wave_steps >= budget;
             }
         }
-        if (cur < 0 && cur != kTravDone) {
+        if (cur < 0 && cur != kDone) {
             if (COUNT) { cn.steps++; if (first_active_lane()) cn.wave_steps++; }
             int code = ~cur;
             leaf_spheres<COUNT>(geo, code >> kLeafBits, (code & (kLeafCap - 1)) + 1, o, dh, tn_min, self, best, cn);
-            if (top != bottom) {
-                top -= kStackStride;
-                cur = pop_ref<G::kPlaneAddressed>(top);
-            } else {
-                cur = kTravDone;
-            }
+            top -= kStackStride;
+            cur = pop_ref<G::kPlaneAddressed>(top);
         }
     }
-    if constexpr (SLICED) sp = (int)((top - bottom) / kStackStride);
+    // (a finished walk leaves top one entry below the bottom: its sp is not used again)
+    if constexpr (SLICED) sp = (int)(top - bottom) / (int)kStackStride;
 }
 
 // ---- hit record ------------------------------------------------------------------------------
@@ -1096,6 +1103,11 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? RT_WG_PER_CU_SCAN : (LDS ? RT_W
     const auto geo = stage_geometry<LDS, QUANT>(sc, s_dyn + rp.stack_depth * kBlock + (kBlock / 64) * accum_words * 2);
     const float4* staged_list = geo.sph;               // the scan reads it when LDS (else it takes the records through scalar loads)
     (void)staged_list;
+    constexpr int kDone = decltype(geo)::kDone;
+    // the entry below every walk's stack (see hit_bvh)
+    if constexpr (BVH) {
+        if constexpr (LDS) *reinterpret_cast<short*>(stack) = (short)kDone; else *stack = kDone;
+    }
     __syncthreads();
 
     const int logP = 31 - __clz(P);
@@ -1162,10 +1174,10 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? RT_WG_PER_CU_SCAN : (LDS ? RT_W
     int q = 0, depth = 0;                              // pixel slot (buffer * P + pixel of the tile), rays traced on the path
     Origin from = no_origin();                         // the primitive the ray starts on
     V3 o = mk(0, 0, 0), d = mk(0, 0, 1), T = mk(1, 1, 1), L = mk(0, 0, 0);
-    // closest-hit query in progress: candidate so far and traversal position.  cur == kTravDone
+    // closest-hit query in progress: candidate so far and traversal position.  cur == kDone
     // on a lane with a path means "ray not started yet".
     Cand c = no_hit();
-    int cur = kTravDone, sp = 0;
+    int cur = kDone, sp = 0;
     for (;;) {
         if (PROF) tq = clk();
         // the older tile's last path has ended: write its pixels
@@ -1235,11 +1247,11 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? RT_WG_PER_CU_SCAN : (LDS ? RT_W
             const RayN rn = normalise(d, rp.t_min);
             // without time slices a query starts and ends inside one trip: its state is local
             Cand c_trip = no_hit();
-            int cur_trip = kTravDone, sp_trip = 0;
+            int cur_trip = kDone, sp_trip = 0;
             Cand& cq = *(SLICED ? &c : &c_trip);
             int& curq = *(SLICED ? &cur : &cur_trip);
             int& spq = *(SLICED ? &sp : &sp_trip);
-            if (curq == kTravDone) {                   // a new ray: always-tested primitives first
+            if (curq == kDone) {                       // a new ray: always-tested primitives first
                 cq = no_hit();
                 hit_always<COUNT, RECTS>(sc, o, d, rn, rp.t_min, from, cq, cn);
                 nrays++;
@@ -1249,9 +1261,9 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? RT_WG_PER_CU_SCAN : (LDS ? RT_W
             }
             if (PROF) { unsigned long long t = clk(); ph[1] += t - tq; tq = t; }
             if constexpr (BVH)
-                if (curq != kTravDone) hit_bvh<COUNT, SLICED>(geo, o, rn, from, stack, rp.slice, rp.leaf_quorum, curq, spq, cq, cn);
+                if (curq != kDone) hit_bvh<COUNT, SLICED>(geo, o, rn, from, stack, rp.slice, rp.leaf_quorum, curq, spq, cq, cn);
             if (PROF) { unsigned long long t = clk(); ph[2] += t - tq; tq = t; }
-            if (curq == kTravDone) {                   // query finished (else: resumed next trip)
+            if (curq == kDone) {                       // query finished (else: resumed next trip)
                 if (shade<COUNT, RECTS>(sc, geo, rp, cq, key, depth, refine, rn, o, d, T, L, from, cn)) {
                     atomicAdd(&accum[q * 3 + 0], to_fixed(L.x));
                     atomicAdd(&accum[q * 3 + 1], to_fixed(L.y));
@@ -1305,6 +1317,7 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(DScene sc, const float* _
                                                        uint32_t flags, Hit* __restrict__ out) {
     __shared__ int s_stack[kMaxStack * kBlock];
     int* stack = s_stack + threadIdx.x;
+    *stack = kTravDone;                                // the entry below the walk's stack (see hit_bvh)
     int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     V3 o = mk(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]);
@@ -1379,8 +1392,9 @@ hipError_t launch_render(const DScene& sc, const DCamera& cam, const DRender& rp
     // when it all fits in a budget that still leaves four workgroups per CU, a copy of the BVH
     // and the sphere list
     DRender r = rp;
-    // one push per inner level at most; stack_depth is in units of kBlock ints
-    const int entries = sc.use_bvh ? sc.bvh_depth + 1 : 1;
+    // one push per inner level at most, and the entry below the stack that ends a walk;
+    // stack_depth is in units of kBlock ints
+    const int entries = sc.use_bvh ? sc.bvh_depth + 2 : 1;
     const size_t accum_bytes = (size_t)(kBlock / 64) * (8 * (64 / rp.lanes_per_pixel) + 1) * sizeof(unsigned long long);
     const size_t geo_bytes = (size_t)sc.n_nodes * kLdsNodeBytes + (size_t)sc.n_sph_padded * 20;
     // the tree walk keeps tree and spheres in LDS up to 40 KB per workgroup (its stack then holds
