@@ -178,6 +178,13 @@ def cpu_baseline_all_cores(wl):
             "seconds": dt, "rays": rays}
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -196,6 +203,9 @@ def main():
                          "1: one frame at a time (what the kernel-trace profile is taken with)")
     ap.add_argument("--float-nodes", action="store_true",
                     help="walk a tree that lives in HBM through its 64-byte float nodes, not the 32-byte quantised ones (A/B)")
+    ap.add_argument("--rehearse-collectives", action="store_true",
+                    help="with one rank: set the process group up all the same and send every frame through the partition's "
+                         "collectives (a gather or an integer reduce among one rank), so that the RCCL code path runs on a one-GPU box")
     ap.add_argument("--check", action="store_true",
                     help="rank 0 also renders every timed frame alone and compares it bit for bit with the assembled one")
     args = ap.parse_args()
@@ -216,8 +226,13 @@ def main():
     device = local_rank if args.backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(device)
     comm_dev = "cuda" if args.backend == "nccl" else "cpu"
-    if world > 1:
+    dist_on = world > 1 or args.rehearse_collectives
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:                                       # not launched by torch.distributed.run
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", device))
         else:
@@ -266,7 +281,7 @@ def main():
     full_rounds = (args.steps // world) * world if partition == "frames+samples" else 0
 
     def plan(k, n_steps):
-        if world == 1:
+        if not dist_on:
             return "own", 0
         if partition == "tiles":
             return "tiles", None
@@ -275,14 +290,14 @@ def main():
         rounds = (n_steps // world) * world
         return ("own", k % world) if k < rounds else ("samples", None)
 
-    tiles = (TILE_ROWS, rank, world) if world > 1 else (0, 0, 0)
-    max_rows = rdist.max_shard_rows(H, TILE_ROWS, world) if (world > 1 and partition == "tiles") else H
+    tiles = (TILE_ROWS, rank, world) if dist_on else (0, 0, 0)
+    max_rows = rdist.max_shard_rows(H, TILE_ROWS, world) if (dist_on and partition == "tiles") else H
     extra_flags = api.RT_FLAG_FLOAT_NODES if args.float_nodes else 0
 
     def P(*a, flags=0, **kw):
         return api.Context.params(*a, flags=flags | extra_flags, **kw)
     fbufs = [torch.zeros((max_rows, W, 4), dtype=torch.float32, device="cuda") for _ in range(n_buf)]
-    ibufs = [torch.zeros((H, W, 4), dtype=torch.int64, device="cuda") for _ in range(n_buf)] if (world > 1 and partition != "tiles") else None
+    ibufs = [torch.zeros((H, W, 4), dtype=torch.int64, device="cuda") for _ in range(n_buf)] if (dist_on and partition != "tiles") else None
     rgb8 = [torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda") for _ in range(n_buf)] if wl.path else None
     my_begin, my_count = rdist.sample_window(SPP, rank, world)
     rendered = [torch.cuda.Event() for _ in range(n_buf)]    # the frame in buffer i is complete
@@ -324,15 +339,16 @@ def main():
         main_stream.wait_event(rendered[i])
         frame = None
         if mode == "tiles":
-            frame = rdist.gather_frame(fbufs[i].cpu() if args.backend == "gloo" else fbufs[i], H, TILE_ROWS, rank, world)
+            frame = rdist.gather_frame(fbufs[i].cpu() if args.backend == "gloo" else fbufs[i], H, TILE_ROWS, rank, world,
+                                       always=args.rehearse_collectives)
         elif mode == "samples":
             if args.backend == "gloo":
                 host = ibufs[i].cpu()
-                rdist.reduce_sums(host, rank, world)
+                rdist.reduce_sums(host, rank, world, always=args.rehearse_collectives)
                 if rank == 0:
                     ibufs[i].copy_(host)
             else:
-                rdist.reduce_sums(ibufs[i], rank, world)
+                rdist.reduce_sums(ibufs[i], rank, world, always=args.rehearse_collectives)
             if rank == 0:
                 post.resolve_sums(ibufs[i].data_ptr(), W * H, fbufs[i].data_ptr())
                 if wl.path:
@@ -358,7 +374,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -410,7 +426,7 @@ def main():
         kernel_ms = sum(a.elapsed_time(b) for a, b in mine) / max(len(mine), 1)
     st = ctxs[lone_step % n_ctx].stats()
     tot = torch.tensor([dt, float(my_rays), kernel_ms], dtype=torch.float64, device=comm_dev)
-    if world > 1:
+    if dist_on:
         mx = tot.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         sm = tot.clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
         dt, kernel_ms, rays_total = float(mx[0]), float(mx[2]), float(sm[1])
@@ -476,7 +492,7 @@ def main():
             want = out8 if wl.path else whole
             ok = ok and bool(torch.equal(want.cpu(), got.cpu()))
         held = torch.tensor([len(kept), int(ok)], dtype=torch.int64, device=comm_dev)
-        if world > 1:
+        if dist_on:
             allh = [torch.zeros_like(held) for _ in range(world)]
             dist.all_gather(allh, held)
         else:
@@ -484,7 +500,7 @@ def main():
         frame_ok = all(int(h[1]) == 1 for h in allh) and sum(int(h[0]) for h in allh) == args.steps
 
     if rank == 0:
-        if world == 1:
+        if not dist_on:
             how = "single GPU"
         elif partition == "tiles":
             how = f"row-tiles x{world}, RCCL gather to rank 0"
@@ -500,7 +516,7 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl.label, "config": args.config, "width": W, "height": H, "spp": SPP,
-                       "accel": args.accel, "tile_rows": TILE_ROWS if (world > 1 and partition == "tiles") else None,
+                       "accel": args.accel, "tile_rows": TILE_ROWS if (dist_on and partition == "tiles") else None,
                        "partition": how,
                        "rays_per_frame": rays_total / args.steps, "lanes_per_pixel": st["lanes_per_pixel"],
                        "bvh_depth": st["bvh_depth"], "bvh_nodes": st["bvh_nodes"], "bvh_coarse_nodes": st["bvh_coarse_nodes"], "bvh_build_ms": build_ms,
@@ -533,7 +549,7 @@ def main():
                 out["speedup_vs_cpu_1thread"] = out["speedup_vs_cpu"]
                 out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(wl)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -48,15 +48,16 @@ def _gather_index(height, tile_rows, world, max_rows, device):
     return _GATHER_INDEX_CACHE[key]
 
 
-def gather_frame(shard, height: int, tile_rows: int, rank: int, world: int, dst: int = 0, group=None):
+def gather_frame(shard, height: int, tile_rows: int, rank: int, world: int, dst: int = 0, group=None, always=False):
     """shard: torch tensor [max_shard_rows, W, C] (rows past this rank's count are padding), the
     same shape on every rank.  Returns the assembled [height, W, C] frame on `dst`, None elsewhere.
     The shards arrive side by side in one buffer and one precomputed row index puts every row in
-    its place."""
+    its place.  always: go through the collective and the index among one rank too (rehearsals of
+    the RCCL path on one GPU)."""
     import torch
     import torch.distributed as dist
 
-    if world == 1:
+    if world == 1 and not always:
         return shard[:height]
     flat = torch.empty((world,) + tuple(shard.shape), dtype=shard.dtype, device=shard.device) if rank == dst else None
     dist.gather(shard, list(flat.unbind(0)) if rank == dst else None, dst=dst, group=group)
@@ -66,7 +67,7 @@ def gather_frame(shard, height: int, tile_rows: int, rank: int, world: int, dst:
     return flat.view((world * shard.shape[0],) + tuple(shard.shape[1:])).index_select(0, index)
 
 
-def reduce_sums(partial, rank: int, world: int, dst: int = 0, group=None):
+def reduce_sums(partial, rank: int, world: int, dst: int = 0, group=None, always=False):
     """Sample-split: every rank rendered the whole frame for its own sample window (sample_begin)
     with RT_FLAG_FIXED_SUMS, `partial` holding the [H, W, 4] integer image as int64 (r, g, b sums in
     32.32 fixed point, sample count).  Integer addition is exact and order-free, so the sum on
@@ -77,7 +78,7 @@ def reduce_sums(partial, rank: int, world: int, dst: int = 0, group=None):
 
     if partial.dtype != torch.int64:
         raise TypeError("reduce_sums takes the RT_FLAG_FIXED_SUMS image as int64")
-    if world > 1:
+    if world > 1 or always:
         dist.reduce(partial, dst=dst, op=dist.ReduceOp.SUM, group=group)
     return partial if rank == dst else None
 

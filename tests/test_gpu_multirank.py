@@ -55,3 +55,20 @@ def test_ranks_share_the_camera_path_by_frames_and_samples():
     assert res["frame_matches_single_gpu"] is True and "4 of 5 steps" in res["config"]["partition"]
     res = _bench("--config", "c5", "--spp", "32", "--steps", "4", "--warmup", "1", ranks=3)
     assert res["frame_matches_single_gpu"] is True and "3 of 4 steps" in res["config"]["partition"]
+
+
+def test_rccl_collectives_among_one_rank():
+    """The collectives as an 8-GPU run issues them (backend nccl = RCCL, device tensors, a
+    communicator bound to the device), among the one rank a one-GPU box can hold: row-tile gather +
+    row index, int64 reduce of the integer sums + resolve; the frames equal the directly rendered
+    ones bit for bit."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for extra in (("--config", "c2", "--partition", "tiles", "--spp", "8"),
+                  ("--config", "c3", "--partition", "samples", "--spp", "9")):
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--rehearse-collectives", "--check", "--no-cpu-baseline",
+               "--steps", "4", "--warmup", "1", *extra]
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=400, env=env, cwd=ROOT)
+        assert out.returncode == 0, out.stderr[-3000:]
+        res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+        assert res["n_gpus"] == 1 and res["frame_matches_single_gpu"] is True
+        assert "RCCL" in res["config"]["partition"]
