@@ -416,25 +416,24 @@ __device__ __forceinline__ void hit_always(const DScene& sc, V3 o, V3 d, const R
         float t;
         if (COUNT) cn.rect++;
         if (i == from_rect) continue;
-        ObjRay q;
-        float inv;
-        if (r.axes >> 8) {                   // instance: a rotation keeps |d|, so t means the same
-            q = to_object(sc.xforms[(r.axes >> 8) - 1], o, d, r.axes & 3, sc.rect_k[i]);
-            inv = polished_rcp(comp(q.d, r.axes & 3));
-        } else {
-            inv = comp(inv_d, r.axes & 3);
-            // the distance to the plane: in float when the plane coordinate is a float (the
-            // subtraction is then as good as the double one rounded), else in double
-            q.o = o; q.d = d;
-            q.num = (r.axes & 64) ? (float)(sc.rect_k[i] - (double)comp(o, r.axes & 3)) : r.k - comp(o, r.axes & 3);
-        }
-        // the rect's axes are the same in every lane: one copy of the test per plane axis, each on the
-        // components themselves, instead of two selects per component picked by number
+        // the record is the same in every lane (it arrives through scalar loads), so what kind of
+        // rect this is and which axis its plane cuts are wave-uniform branches: one copy of the test
+        // per plane axis, each on the ray's components themselves
         bool hit;
         const int ka = __builtin_amdgcn_readfirstlane(r.axes & 3);
-        if (ka == 0) hit = rect_test<0>(r, q.num, inv, q.o, q.d, t_min, kInf, t);
-        else if (ka == 1) hit = rect_test<1>(r, q.num, inv, q.o, q.d, t_min, kInf, t);
-        else hit = rect_test<2>(r, q.num, inv, q.o, q.d, t_min, kInf, t);
+        if (r.axes >> 8) {                   // instance: a rotation keeps |d|, so t means the same
+            const ObjRay q = to_object(sc.xforms[(r.axes >> 8) - 1], o, d, ka, sc.rect_k[i]);
+            if (ka == 0) hit = rect_test<0>(r, q.num, polished_rcp(q.d.x), q.o, q.d, t_min, kInf, t);
+            else if (ka == 1) hit = rect_test<1>(r, q.num, polished_rcp(q.d.y), q.o, q.d, t_min, kInf, t);
+            else hit = rect_test<2>(r, q.num, polished_rcp(q.d.z), q.o, q.d, t_min, kInf, t);
+        } else {
+            // the distance to the plane: in float when the plane coordinate is a float (the
+            // subtraction is then as good as the double one rounded), else in double
+            const bool k64 = (r.axes & 64) != 0;
+            if (ka == 0) hit = rect_test<0>(r, k64 ? (float)(sc.rect_k[i] - (double)o.x) : r.k - o.x, inv_d.x, o, d, t_min, kInf, t);
+            else if (ka == 1) hit = rect_test<1>(r, k64 ? (float)(sc.rect_k[i] - (double)o.y) : r.k - o.y, inv_d.y, o, d, t_min, kInf, t);
+            else hit = rect_test<2>(r, k64 ? (float)(sc.rect_k[i] - (double)o.z) : r.k - o.z, inv_d.z, o, d, t_min, kInf, t);
+        }
         if (hit) {
             float tn = t * rn.len;
             if (better(tn, r.obj, best)) { best.tn = tn; best.kind = 2; best.idx = i; best.obj = r.obj; }
