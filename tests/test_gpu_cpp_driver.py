@@ -44,3 +44,34 @@ def test_cpp_driver_matches_python_host(tmp_path, oracle):
     want = oracle.write_color(img[..., :3].astype(np.float64).reshape(-1, 3), spp).reshape(H, W, 3)
     assert ppm.p3_bytes(want.astype(np.uint8)) == out.stdout
     ctx.close()
+
+
+def test_cpp_sequence_driver_writes_the_python_drivers_files(tmp_path):
+    """examples/sequence_main.cpp (the frame loop of cuda/main.cu:557-591 in C++: update_scene per
+    frame, two contexts in flight, rt_quantize, image_<frame>_low.ppm) against
+    raytrace_amd.sequence.render_sequence: the same files, byte for byte, in P3 and in P6."""
+    exe = os.path.join(ROOT, "examples", "sequence")
+    if not os.path.exists(exe):
+        pytest.fail("examples/sequence is not built: run __graft_entry__.build()")
+    from raytrace_amd import api, scene as S, sequence
+    rec = S.rtiow_records()
+    scene_txt = tmp_path / "scene.txt"
+    with open(scene_txt, "w") as f:
+        for o in rec:
+            f.write(" ".join(repr(float(x)) for x in o) + "\n")
+    W, H, spp, first, n = 96, 54, 4, 148, 5                 # frames either side of the path's first change of motion at 150
+    ctx = api.Context(0)
+    ctx.upload_scene(S.flatten(S.world_from_records(rec)))
+    for fmt in ("p3", "p6"):
+        cpp_dir, py_dir = tmp_path / f"cpp_{fmt}", tmp_path / f"py_{fmt}"
+        subprocess.run([exe, str(scene_txt), str(cpp_dir), str(W), str(H), str(spp), str(first), str(n), fmt],
+                       capture_output=True, check=True, timeout=120)
+        cam = S.rtiow_camera(float(np.float32(W / H)))
+        done = sequence.render_sequence(ctx, cam, n, W, H, spp, str(py_dir), max_depth=25, seed=1, fmt=fmt, first_frame=first)
+        assert [d[0] for d in done] == list(range(first, first + n))
+        for frame in range(first, first + n):
+            name = os.path.join("ppm_images", f"image_{frame}_low.ppm")
+            got, want = open(cpp_dir / name, "rb").read(), open(py_dir / name, "rb").read()
+            assert got == want, (fmt, frame)
+        assert sorted(os.listdir(cpp_dir / "ppm_images")) == sorted(os.listdir(py_dir / "ppm_images"))
+    ctx.close()
