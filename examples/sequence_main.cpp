@@ -17,7 +17,6 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
-#include <cstring>
 #include <fstream>
 #include <iostream>
 #include <string>
@@ -46,37 +45,6 @@ static sceneobject_list load_world(const char* path) {
     std::cerr << #call << ": " << hipGetErrorString(e_) << "\n"; return 1; } } while (0)
 #define RT_CHECK(ctx, call) do { int rc_ = (call); if (rc_ != RT_OK) { \
     std::cerr << #call << ": " << rt_last_error(ctx) << "\n"; return 1; } } while (0)
-
-// cuda/main.cu:358-383 (rows top to bottom, one pixel per line), on bytes that are already write_color's
-static bool write_ppm(const std::string& path, int w, int h, const std::vector<uint8_t>& rgb, bool text) {
-    std::string out;
-    if (text) {
-        // decimal text of a byte from a table: formatting 2 million pixels through snprintf takes
-        // longer than rendering them
-        static char digits[256][4];
-        static int len[256];
-        if (!len[0]) for (int v = 0; v < 256; v++) len[v] = std::snprintf(digits[v], 4, "%d", v);
-        std::string head = "P3\n" + std::to_string(w) + " " + std::to_string(h) + "\n255\n";
-        out.resize(head.size() + (size_t)w * h * 12);
-        char* q = &out[0];
-        std::memcpy(q, head.data(), head.size()); q += head.size();
-        for (int j = h - 1; j >= 0; j--)
-            for (int i = 0; i < w; i++) {
-                const uint8_t* p = &rgb[3 * ((size_t)j * w + i)];
-                for (int c = 0; c < 3; c++) {
-                    std::memcpy(q, digits[p[c]], 4); q += len[p[c]];      // (the table's fourth byte is overwritten next)
-                    *q++ = c < 2 ? ' ' : '\n';
-                }
-            }
-        out.resize((size_t)(q - out.data()));
-    } else {
-        out = "P6\n" + std::to_string(w) + " " + std::to_string(h) + "\n255\n";
-        for (int j = h - 1; j >= 0; j--) out.append(reinterpret_cast<const char*>(&rgb[3 * (size_t)j * w]), (size_t)3 * w);
-    }
-    std::ofstream f(path, std::ofstream::binary | std::ofstream::trunc);
-    f.write(out.data(), (std::streamsize)out.size());
-    return (bool)f;
-}
 
 int main(int argc, char** argv) {
     if (argc < 8) { std::cerr << "usage: sequence scene.txt out_dir width height spp first_frame n_frames [p3|p6]\n"; return 2; }
@@ -122,7 +90,8 @@ int main(int argc, char** argv) {
         RT_CHECK(ctx[s], rt_get_stats(ctx[s], &st));
         rays += st.rays; kernel_ms += st.kernel_ms;
         const std::string path = out_dir + "/ppm_images/image_" + std::to_string(frame) + "_low.ppm";
-        if (!write_ppm(path, W, H, rgb_host[s], text)) { std::cerr << "cannot write " << path << "\n"; return 1; }
+        // output_image (cuda/main.cu:358-383) on bytes that are already write_color's
+        if (rt_write_ppm(path.c_str(), rgb_host[s].data(), W, H, text ? 0 : 1) != RT_OK) { std::cerr << rt_image_last_error() << "\n"; return 1; }
         return 0;
     };
     for (int frame = 0; frame < first + n_frames; frame++) {

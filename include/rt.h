@@ -228,6 +228,14 @@ int rt_load_jpeg_file(const char* path, int32_t* width, int32_t* height, uint8_t
 void rt_free_image(uint8_t* rgb8);
 const char* rt_image_last_error(void);
 
+/* Frame files (host side, no context): output_image (cuda/main.cu:358-383) and the output loop of
+ * main.cc:109-126 -- "P3", width height, 255, then one pixel per line as decimal text, top row first;
+ * binary != 0 writes the same pixels as a binary "P6" file instead.  rgb8: height x width x 3 bytes with
+ * row 0 = the BOTTOM row, which is what rt_quantize leaves (the reference's loops count j downwards
+ * for the same reason).  Errors: RT_ERR_INVALID (bad arguments, or the file cannot be written: text
+ * from rt_image_last_error). */
+int rt_write_ppm(const char* path, const uint8_t* rgb8, int32_t width, int32_t height, int32_t binary);
+
 #ifdef __cplusplus
 }
 #endif

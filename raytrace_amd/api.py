@@ -20,7 +20,7 @@ RT_FLAG_MEAN, RT_FLAG_NO_REFINE, RT_FLAG_COUNTERS, RT_FLAG_PHASE_CLOCKS, RT_FLAG
 EXPORTS = ["rt_create", "rt_destroy", "rt_set_stream", "rt_upload_scene", "rt_set_camera",
            "rt_shard_rows", "rt_render", "rt_render_host", "rt_trace_primary", "rt_trace_primary_noalloc", "rt_quantize",
            "rt_resolve_sums", "rt_get_stats", "rt_last_error", "rt_version",
-           "rt_decode_jpeg", "rt_load_jpeg_file", "rt_free_image", "rt_image_last_error"]
+           "rt_decode_jpeg", "rt_load_jpeg_file", "rt_free_image", "rt_image_last_error", "rt_write_ppm"]
 
 
 class RtError(RuntimeError):
@@ -118,6 +118,7 @@ def lib():
         L.rt_free_image.argtypes = [C.c_void_p]
         L.rt_free_image.restype = None
         L.rt_image_last_error.restype = C.c_char_p
+        L.rt_write_ppm.argtypes = [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
         _lib = L
     return _lib
 
@@ -141,6 +142,16 @@ def decode_jpeg(data: bytes) -> np.ndarray:
 def load_jpeg_file(path) -> np.ndarray:
     w, h, out = C.c_int32(), C.c_int32(), C.c_void_p()
     return _take_image(lib().rt_load_jpeg_file(os.fsencode(path), C.byref(w), C.byref(h), C.byref(out)), w, h, out)
+
+
+def write_ppm(path, rgb8_bottom_up, binary=False) -> None:
+    """uint8 [height, width, 3] with row 0 = bottom row -> a P3 (text) or P6 file (rt_write_ppm)."""
+    a = np.ascontiguousarray(rgb8_bottom_up, np.uint8)
+    if a.ndim != 3 or a.shape[2] != 3:
+        raise ValueError("write_ppm takes [height, width, 3] bytes")
+    rc = lib().rt_write_ppm(os.fsencode(path), a.ctypes.data, a.shape[1], a.shape[0], 1 if binary else 0)
+    if rc != RT_OK:
+        raise RtError(rc, lib().rt_image_last_error().decode())
 
 
 def _ptr(a):

@@ -666,6 +666,44 @@ int rt_load_jpeg_file(const char* path, int32_t* width, int32_t* height, uint8_t
 
 void rt_free_image(uint8_t* rgb8) { std::free(rgb8); }
 
+// cuda/main.cu:358-383 / main.cc:109-126: "P3", size, 255, then one pixel per line, top row first.
+// The decimal text of a byte comes from a table (formatting the six million numbers of a 1080p
+// frame through printf takes three times as long as rendering them).
+int rt_write_ppm(const char* path, const uint8_t* rgb8, int32_t width, int32_t height, int32_t binary) {
+    if (!path || !rgb8 || width < 1 || height < 1) { g_error = "rt_write_ppm: null path or pixels, or an empty image"; return RT_ERR_INVALID; }
+    const size_t w = (size_t)width, h = (size_t)height;
+    char head[64];
+    const int head_len = std::snprintf(head, sizeof head, "P%d\n%d %d\n255\n", binary ? 6 : 3, width, height);
+    std::vector<char> out;
+    if (binary) {
+        out.resize((size_t)head_len + 3 * w * h);
+        std::memcpy(out.data(), head, (size_t)head_len);
+        for (size_t j = 0; j < h; j++) std::memcpy(out.data() + head_len + 3 * w * j, rgb8 + 3 * w * (h - 1 - j), 3 * w);
+    } else {
+        char digits[256][4];
+        int len[256];
+        for (int v = 0; v < 256; v++) len[v] = std::snprintf(digits[v], 4, "%d", v);
+        out.resize((size_t)head_len + 12 * w * h);             // at most three digits and a separator per number
+        char* q = out.data();
+        std::memcpy(q, head, (size_t)head_len); q += head_len;
+        for (size_t j = h; j-- > 0;)
+            for (size_t i = 0; i < w; i++) {
+                const uint8_t* p = rgb8 + 3 * (j * w + i);
+                for (int c = 0; c < 3; c++) {
+                    std::memcpy(q, digits[p[c]], 4); q += len[p[c]];    // (what follows the digits is overwritten next)
+                    *q++ = c < 2 ? ' ' : '\n';
+                }
+            }
+        out.resize((size_t)(q - out.data()));
+    }
+    FILE* f = std::fopen(path, "wb");
+    if (!f) { g_error = std::string("cannot open ") + path + " for writing"; return RT_ERR_INVALID; }
+    const size_t put = std::fwrite(out.data(), 1, out.size(), f);
+    const int closed = std::fclose(f);
+    if (put != out.size() || closed != 0) { g_error = std::string("short write to ") + path; return RT_ERR_INVALID; }
+    return RT_OK;
+}
+
 const char* rt_image_last_error(void) { return g_error.c_str(); }
 
 }  // extern "C"

@@ -7,23 +7,34 @@ import numpy as np
 
 
 def p3_bytes(rgb8_bottom_up: np.ndarray) -> bytes:
-    """rgb8_bottom_up: [H, W, 3] uint8 with row 0 = bottom row (the framebuffer orientation)."""
+    """rgb8_bottom_up: [H, W, 3] uint8 with row 0 = bottom row (the framebuffer orientation).
+    The text is laid out with array operations (a 1080p frame is six million numbers: a Python
+    loop over them takes longer than a hundred frames take to render)."""
     h, w, _ = rgb8_bottom_up.shape
-    top_down = rgb8_bottom_up[::-1].reshape(-1, 3)
-    body = "\n".join(f"{r} {g} {b}" for r, g, b in top_down.tolist())
-    return f"P3\n{w} {h}\n255\n{body}\n".encode("ascii")
+    v = np.ascontiguousarray(rgb8_bottom_up[::-1]).reshape(-1).astype(np.int64)
+    n_digits = 1 + (v >= 10) + (v >= 100)
+    end = np.cumsum(n_digits + 1)                           # one past each number's separator
+    out = np.empty(int(end[-1]) if v.size else 0, np.uint8)
+    sep = np.full(v.size, ord(" "), np.uint8)
+    sep[2::3] = ord("\n")                                   # one pixel per line
+    out[end - 1] = sep
+    out[end - 2] = ord("0") + v % 10
+    tens = v >= 10
+    out[end[tens] - 3] = ord("0") + (v[tens] // 10) % 10
+    hundreds = v >= 100
+    out[end[hundreds] - 4] = ord("0") + v[hundreds] // 100
+    return f"P3\n{w} {h}\n255\n".encode("ascii") + out.tobytes()
 
 
 def write_p3(path: str, rgb8_bottom_up: np.ndarray) -> None:
-    with open(path, "wb") as f:
-        f.write(p3_bytes(rgb8_bottom_up))
+    """The file p3_bytes describes, written by the library (rt_write_ppm: 8 ms for a 1080p frame)."""
+    from . import api
+    api.write_ppm(path, rgb8_bottom_up, binary=False)
 
 
 def write_p6(path: str, rgb8_bottom_up: np.ndarray) -> None:
-    h, w, _ = rgb8_bottom_up.shape
-    with open(path, "wb") as f:
-        f.write(f"P6\n{w} {h}\n255\n".encode("ascii"))
-        f.write(np.ascontiguousarray(rgb8_bottom_up[::-1]).tobytes())
+    from . import api
+    api.write_ppm(path, rgb8_bottom_up, binary=True)
 
 
 def frame_name(frame: int, quality: str = "low") -> str:

@@ -155,3 +155,23 @@ def test_cpp_facade_walks_the_camera_path_like_the_python_facade(tmp_path):
     c2.rotate_camera_y(400.0)
     got = np.array([float(x) for x in lines[600].split()[1:]]).astype(np.float32)
     assert np.array_equal(got, np.array([*c2.look_from, *c2.angles]).astype(np.float32)), (got, c2.look_from, c2.angles)
+
+
+def test_ppm_files_of_the_library_match_the_text_layout(tmp_path):
+    """rt_write_ppm (output_image, cuda/main.cu:358-383): the P3 file is p3_bytes' text (every digit
+    count, rows top to bottom), the P6 file the same pixels in binary; bad arguments are errors."""
+    from raytrace_amd import api, ppm
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (7, 5, 3), dtype=np.uint8)
+    img[0, 0] = (0, 9, 10)
+    img[6, 4] = (99, 100, 255)
+    ppm.write_p3(str(tmp_path / "a.ppm"), img)
+    got = open(tmp_path / "a.ppm", "rb").read()
+    want = ("P3\n5 7\n255\n" + "".join(f"{r} {g} {b}\n" for r, g, b in img[::-1].reshape(-1, 3).tolist())).encode()
+    assert got == want == ppm.p3_bytes(img)
+    ppm.write_p6(str(tmp_path / "b.ppm"), img)
+    assert open(tmp_path / "b.ppm", "rb").read() == b"P6\n5 7\n255\n" + img[::-1].tobytes()
+    with pytest.raises(api.RtError):
+        api.write_ppm(str(tmp_path / "no_such_dir" / "c.ppm"), img)
+    with pytest.raises(ValueError):
+        api.write_ppm(str(tmp_path / "d.ppm"), img[..., :2])
