@@ -108,7 +108,7 @@ struct DRender {
     uint32_t flags;
     int lanes_per_pixel;                    // K: power of two, 1..64; a wave's tile holds 64/K pixels
     float inv_wm1, inv_hm1;                 // 1/(W-1), 1/(H-1)  (main.cc:117-118)
-    int stack_depth;                        // entries per lane of the LDS traversal stack
+    int stack_depth;                        // size of the LDS traversal stack in units of kBlock ints (tree depth + 2 entries per lane; 16-bit entries with the tree in LDS)
     int slice;                              // node steps a wave spends on traversal per trip (0 = no limit, 0x7fffffff = choose at launch)
     int leaf_quorum;                        // time-sliced walk: leaves are tested once (lanes waiting at a leaf) x this >= lanes still walking (0 = wait for all, -1 = default)
 };

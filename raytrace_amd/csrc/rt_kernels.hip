@@ -113,11 +113,13 @@ __device__ __forceinline__ bool sphere_test(float4 s, V3 o, V3 dh, float lo_near
     float gap = fmaf(s.w, s.w, -dot(l, l));         // r^2 - (distance of the centre from the line)^2, as in hit_list
     if (!(gap >= 0.0f)) return false;
     float thc = __builtin_amdgcn_sqrtf(gap);        // 1 ulp; the winner's root is polished in double
-    float root = tca - thc;
-    if (!(root >= lo_near && root <= tn_max)) {
-        root = tca + thc;
-        if (!(root >= lo_far && root <= tn_max)) return false;
-    }
+    // sphere.h:29-37: the near root, else the far one.  A near root beyond tn_max leaves the far one
+    // beyond it as well, so the far root is only ever wanted when the near one lies before its
+    // lower bound: one select and three compares, no branch
+    const float near_root = tca - thc;
+    const bool use_far = !(near_root >= lo_near);
+    const float root = use_far ? tca + thc : near_root, lo = use_far ? lo_far : lo_near;
+    if (!(root >= lo && root <= tn_max)) return false;
     tn_out = root;
     return true;
 }
@@ -340,7 +342,11 @@ __device__ __forceinline__ void leaf_sphere(const G& geo, int i, float4 s, V3 o,
     if (sphere_test(s, o, dh, lo, lo, best.tn, tn)) {
         int obj = geo.obj(i);
         if (COUNT) cn.sph_hit++;
-        if (better(tn, obj, best)) { best.tn = tn; best.kind = 0; best.idx = i; best.obj = obj; }
+        // the range test let through tn <= best.tn, so better() comes down to "not an exact tie that
+        // the earlier list entry loses": one compare on the common path instead of four
+        bool take = true;
+        if (tn == best.tn) take = obj > best.obj;
+        if (take) { best.tn = tn; best.kind = 0; best.idx = i; best.obj = obj; }
     }
 }
 
@@ -1077,7 +1083,7 @@ __device__ __forceinline__ float from_fixed(unsigned long long q) { return (floa
 // (pixel, sample) of the tile are numbered sample-major and handed out dynamically: whenever
 // lanes are free (their path ended) they take the next units, so every trip of the loop traces
 // one ray on all 64 lanes until the tile runs out of samples, whatever the path lengths were.
-// Dynamic LDS: [traversal stack: stack_depth x kBlock ints][accumulators and pixel tables: 4 waves x (8P + 1) u64]
+// Dynamic LDS: [traversal stack: stack_depth x kBlock ints, a lane's column starting with the entry that ends a walk][accumulators and pixel tables: 4 waves x (8P + 1) u64]
 // then, for the LDS-resident variant, [nodes][spheres][list positions].
 // MODE: 0 linear scan, 1 BVH, 2 BVH walked in time slices.  Each combination is a kernel of its
 // own: code that a scene never runs (rects, the scan, the tree walk) still costs the code that

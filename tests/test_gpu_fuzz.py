@@ -72,7 +72,7 @@ def _random_scene(S, rng):
 # |unit direction|^2 - 1 (1e-7) times the squared distance is as large as the discriminant
 # 18788 has a checker texture that changes sign across a rect's plane within an ulp of the plane's
 # coordinate
-_KEPT_SEEDS = [2161, 5899, 14114, 18788, 56104]        # 56104: a root 6.6e-7 above t_min
+_KEPT_SEEDS = [2161, 5899, 14114, 18788, 56104, 343970, 345337]   # 56104: a root 6.6e-7 above t_min; 343970: one 1 % above it, 2000 from the origin; 345337: no ray meets anything
 _N_SEEDS = int(__import__("os").environ.get("RT_FUZZ_SEEDS", "40"))
 _FIRST_SEED = int(__import__("os").environ.get("RT_FUZZ_FIRST", "0"))          # long runs by hand, in parts
 
@@ -99,19 +99,26 @@ def test_random_scene(seed, oracle):
         ctx.set_camera(**cam)
         hits = ctx.trace_primary(rays)
         bad = hits["id"] != want["id"]
-        # a root within a part in a thousand of t_min is the other kind of ray single precision cannot
-        # decide like double (the sphere records are rounded to float: 2e-7 of the coordinates):
-        # the same sphere is then hit at its far side instead; counted with the silhouette rays
-        bad |= (np.minimum(hits["t"], want["t"]) < 0.001 * 1.001) & (want["id"] >= 0)
+        # a root that close to t_min is the other kind of ray single precision cannot decide like
+        # double: the sphere records are rounded to float, which moves a surface by 1e-7 of its
+        # coordinates (1e-4 in a scene that stands 2000 from the origin, a tenth of the distance t_min
+        # stands for); the same sphere is then hit at its far side instead.  Counted with the
+        # silhouette rays.  (Scene 343970 of the generator: a root 1 % above t_min, 2000 from the origin.)
+        reach = np.abs(rays[:, :3]).max(axis=1) + 4.0 * scale
+        near_t_min = 0.001 * 1.001 + 5e-7 * reach / np.linalg.norm(rays[:, 3:], axis=1)
+        bad |= (np.minimum(hits["t"], want["t"]) < near_t_min) & (want["id"] >= 0)
         assert bad.sum() <= 3, (accel, int(bad.sum()), np.where(bad)[0][:5], hits["id"][bad][:5], want["id"][bad][:5])
         # a ray that grazes its sphere closer than cos = 1e-3 has no well-defined t in single
         # precision (the golden rays keep clear of silhouettes for the same reason)
         cos = np.abs(np.sum(want["n"] * _unit(rays[:, 3:]), axis=1))
         ok = ~bad & (want["id"] >= 0) & (cos > 1e-3)
-        rel = np.abs(hits["t"][ok] - want["t"][ok]) / np.abs(want["t"][ok])
-        assert rel.max() <= 1e-5, (accel, float(rel.max()))
-        assert np.abs(hits["n"][ok] - want["n"][ok]).max() <= 1e-5
-        assert np.array_equal(hits["front_face"][ok], want["front"][ok])
+        if ok.any():                                               # (a scene none of the rays meets: nothing to compare)
+            rel = np.abs(hits["t"][ok] - want["t"][ok]) / np.abs(want["t"][ok])
+            worst = np.where(ok)[0][int(np.argmax(rel))]
+            assert rel.max() <= 1e-5, (accel, float(rel.max()), int(worst), float(hits["t"][worst]), float(want["t"][worst]),
+                                       int(want["id"][worst]), rays[worst].tolist(), float(scale), np.asarray(offset).tolist())
+            assert np.abs(hits["n"][ok] - want["n"][ok]).max() <= 1e-5
+            assert np.array_equal(hits["front_face"][ok], want["front"][ok])
         img = ctx.render_host(api.Context.params(W, H, spp, 50, 77 + seed))
         st = ctx.stats()
         if accel != api.RT_ACCEL_LIST:
@@ -198,10 +205,14 @@ def test_random_sphere_field(seed, oracle):
         ctx.set_camera(**cam)
         hits = ctx.trace_primary(rays)
         bad = hits["id"] != want["id"]
-        # a root within a part in a thousand of t_min is the other kind of ray single precision cannot
-        # decide like double (the sphere records are rounded to float: 2e-7 of the coordinates):
-        # the same sphere is then hit at its far side instead; counted with the silhouette rays
-        bad |= (np.minimum(hits["t"], want["t"]) < 0.001 * 1.001) & (want["id"] >= 0)
+        # a root that close to t_min is the other kind of ray single precision cannot decide like
+        # double: the sphere records are rounded to float, which moves a surface by 1e-7 of its
+        # coordinates (1e-4 in a scene that stands 2000 from the origin, a tenth of the distance t_min
+        # stands for); the same sphere is then hit at its far side instead.  Counted with the
+        # silhouette rays.  (Scene 343970 of the generator: a root 1 % above t_min, 2000 from the origin.)
+        reach = np.abs(rays[:, :3]).max(axis=1) + 4.0 * scale
+        near_t_min = 0.001 * 1.001 + 5e-7 * reach / np.linalg.norm(rays[:, 3:], axis=1)
+        bad |= (np.minimum(hits["t"], want["t"]) < near_t_min) & (want["id"] >= 0)
         assert bad.sum() <= 3, (accel, int(bad.sum()), np.where(bad)[0][:5], hits["id"][bad][:5], want["id"][bad][:5])
         cos = np.abs(np.sum(want["n"] * _unit(rays[:, 3:]), axis=1))
         ok = ~bad & (want["id"] >= 0) & (cos > 1e-3)
