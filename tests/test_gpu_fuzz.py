@@ -106,7 +106,8 @@ def test_random_scene(seed, oracle):
         # silhouette rays.  (Scene 343970 of the generator: a root 1 % above t_min, 2000 from the origin.)
         reach = np.abs(rays[:, :3]).max(axis=1) + 4.0 * scale
         near_t_min = 0.001 * 1.001 + 5e-7 * reach / np.linalg.norm(rays[:, 3:], axis=1)
-        bad |= (np.minimum(hits["t"], want["t"]) < near_t_min) & (want["id"] >= 0)
+        near = (np.minimum(hits["t"], want["t"]) < near_t_min) & (want["id"] >= 0)
+        bad |= near & ~(np.abs(hits["t"] - want["t"]) <= 1e-5 * np.abs(want["t"]))     # (a root that close AND decided the other way)
         assert bad.sum() <= 3, (accel, int(bad.sum()), np.where(bad)[0][:5], hits["id"][bad][:5], want["id"][bad][:5])
         # a ray that grazes its sphere closer than cos = 1e-3 has no well-defined t in single
         # precision (the golden rays keep clear of silhouettes for the same reason)
@@ -212,7 +213,8 @@ def test_random_sphere_field(seed, oracle):
         # silhouette rays.  (Scene 343970 of the generator: a root 1 % above t_min, 2000 from the origin.)
         reach = np.abs(rays[:, :3]).max(axis=1) + 4.0 * scale
         near_t_min = 0.001 * 1.001 + 5e-7 * reach / np.linalg.norm(rays[:, 3:], axis=1)
-        bad |= (np.minimum(hits["t"], want["t"]) < near_t_min) & (want["id"] >= 0)
+        near = (np.minimum(hits["t"], want["t"]) < near_t_min) & (want["id"] >= 0)
+        bad |= near & ~(np.abs(hits["t"] - want["t"]) <= 1e-5 * np.abs(want["t"]))     # (a root that close AND decided the other way)
         assert bad.sum() <= 3, (accel, int(bad.sum()), np.where(bad)[0][:5], hits["id"][bad][:5], want["id"][bad][:5])
         cos = np.abs(np.sum(want["n"] * _unit(rays[:, 3:]), axis=1))
         ok = ~bad & (want["id"] >= 0) & (cos > 1e-3)
