@@ -179,7 +179,10 @@ int rt_set_camera(rt_context* ctx, const rt_camera_desc* camera);
 int rt_shard_rows(int32_t height, int32_t tile_rows, int32_t tile_first, int32_t tile_step);
 
 /* Render into DEVICE memory: rgba_device holds rt_shard_rows(..) * width float4 (with
- * RT_FLAG_FIXED_SUMS: as many 4 x uint64_t).  Asynchronous on the context's stream. */
+ * RT_FLAG_FIXED_SUMS: as many 4 x uint64_t).  Asynchronous on the context's stream.  Where the HIP
+ * runtime knows the allocation the pointer lies in (hipMalloc and the like), a buffer that ends before
+ * the last byte the call writes is RT_ERR_INVALID, checked on the host before anything is launched;
+ * rt_quantize and rt_resolve_sums check their buffers the same way. */
 int rt_render(rt_context* ctx, const rt_render_params* params, float* rgba_device);
 /* Same into HOST memory; returns when the image is there. */
 int rt_render_host(rt_context* ctx, const rt_render_params* params, float* rgba_host);

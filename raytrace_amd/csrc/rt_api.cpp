@@ -590,12 +590,33 @@ int rt_set_camera(rt_context* ctx, const rt_camera_desc* c) {
     return RT_OK;
 }
 
+// A caller's device buffer is a bare pointer at this boundary, and a kernel that writes past the end
+// of one faults the GPU (which on a shared machine takes other people's work with it).  Where the
+// runtime knows the allocation a pointer lies in, its extent is checked on the host before anything
+// is launched: a buffer that is too small is an error code.  Pointers the runtime cannot place
+// (sub-allocators over mapped ranges, memory of other APIs) are taken on trust, as before.
+static int check_device_range(rt_context* ctx, const void* p, size_t bytes, const char* what) {
+    hipDeviceptr_t base = nullptr;
+    size_t size = 0;
+    if (hipMemGetAddressRange(&base, &size, const_cast<void*>(p)) != hipSuccess) {
+        (void)hipGetLastError();                       // (not an error of this call: the pointer is just not the runtime's)
+        return RT_OK;
+    }
+    const size_t off = (size_t)((const char*)p - (const char*)base);
+    if (off > size || bytes > size - off)
+        return fail(ctx, RT_ERR_INVALID, std::string(what) + ": the device buffer ends " + std::to_string(size - std::min(off, size)) +
+                                         " bytes after the pointer, " + std::to_string(bytes) + " are written");
+    return RT_OK;
+}
+
 int rt_render(rt_context* ctx, const rt_render_params* params, float* rgba_device) {
     rt::DRender rp{};
     int rc = validate_render(ctx, params, &rp);
     if (rc) return rc;
     if (!rgba_device) return fail(ctx, RT_ERR_INVALID, "null output");
     DeviceGuard g(ctx->device);
+    const size_t bytes = (size_t)rp.rows * rp.width * ((rp.flags & RT_FLAG_FIXED_SUMS) ? 4 * sizeof(uint64_t) : sizeof(float4));
+    if ((rc = check_device_range(ctx, rgba_device, bytes, "rt_render"))) return rc;
     return do_render(ctx, rp, reinterpret_cast<float4*>(rgba_device));
 }
 
@@ -673,6 +694,11 @@ int rt_quantize(rt_context* ctx, const float* rgba_device, int64_t n_pixels, int
     if (n_pixels < 0 || spp < 1 || (n_pixels > 0 && (!rgba_device || !rgb8_device)))
         return fail(ctx, RT_ERR_INVALID, "rt_quantize: bad arguments");
     DeviceGuard g(ctx->device);
+    if (n_pixels > 0) {
+        int rc;
+        if ((rc = check_device_range(ctx, rgba_device, (size_t)n_pixels * sizeof(float4), "rt_quantize (sums)")) ||
+            (rc = check_device_range(ctx, rgb8_device, (size_t)n_pixels * 3, "rt_quantize (bytes)"))) return rc;
+    }
     RT_HIP(ctx, rt::launch_quantize(reinterpret_cast<const float4*>(rgba_device), n_pixels, spp, rgb8_device, ctx->stream));
     return RT_OK;
 }
@@ -682,6 +708,11 @@ int rt_resolve_sums(rt_context* ctx, const uint64_t* sums_device, int64_t n_pixe
     if (n_pixels < 0 || (n_pixels > 0 && (!sums_device || !rgba_device)))
         return fail(ctx, RT_ERR_INVALID, "rt_resolve_sums: bad arguments");
     DeviceGuard g(ctx->device);
+    if (n_pixels > 0) {
+        int rc;
+        if ((rc = check_device_range(ctx, sums_device, (size_t)n_pixels * 4 * sizeof(uint64_t), "rt_resolve_sums (sums)")) ||
+            (rc = check_device_range(ctx, rgba_device, (size_t)n_pixels * sizeof(float4), "rt_resolve_sums (image)"))) return rc;
+    }
     RT_HIP(ctx, rt::launch_resolve(reinterpret_cast<const unsigned long long*>(sums_device), n_pixels, mean != 0,
                                    reinterpret_cast<float4*>(rgba_device), ctx->stream));
     return RT_OK;

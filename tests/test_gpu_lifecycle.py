@@ -110,3 +110,52 @@ def test_contexts_on_threads_render_the_same_bits(api, rtiow_flat):
     assert not err, err
     for o in out:
         assert o is not None and np.array_equal(o, want)
+
+
+def test_a_device_buffer_that_is_too_small_is_an_error_not_a_fault(api, rtiow_flat):
+    """rt_render / rt_quantize / rt_resolve_sums write into bare device pointers; where the runtime
+    knows the allocation, a buffer that ends too early is refused on the host (a kernel writing past
+    it would fault the GPU).  Checked on raw hipMalloc'ed buffers, the case the runtime can place exactly."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    hip.hipFree.argtypes = [ctypes.c_void_p]
+    W, H = 64, 48
+
+    def dev(nbytes):
+        p = ctypes.c_void_p()
+        assert hip.hipMalloc(ctypes.byref(p), nbytes) == 0
+        return p
+
+    full, short = dev(W * H * 16), dev(W * H * 16 - 4096)
+    # the runtime must place these pointers exactly, or the library takes them on trust (and this
+    # test must not hand it a buffer that is too small)
+    hip.hipMemGetAddressRange.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t), ctypes.c_void_p]
+    base, size = ctypes.c_void_p(), ctypes.c_size_t()
+    if hip.hipMemGetAddressRange(ctypes.byref(base), ctypes.byref(size), short) != 0 or size.value != W * H * 16 - 4096 \
+            or base.value != short.value:
+        pytest.skip("the runtime does not report the extent of a hipMalloc allocation exactly")
+    c = api.Context(0)
+    c.upload_scene(rtiow_flat)
+    c.set_camera(**CAM)
+    sums = dev(W * H * 32)
+    rgb = dev(W * H * 3)
+    p = api.Context.params(W, H, 2, 50, 1)
+    c.render(p, full.value)                                                     # fits
+    c.render(api.Context.params(W, H, 2, 50, 1, tiles=(4, 0, 2)), short.value)   # half the rows fit the shorter buffer
+    for bad in (lambda: c.render(p, short.value),
+                lambda: c.render(p, full.value + 16),                           # a pointer into the buffer: what is left counts
+                lambda: c.render(api.Context.params(W, H, 2, 50, 1, flags=api.RT_FLAG_FIXED_SUMS), full.value),
+                lambda: c.quantize(short.value, W * H, 2, rgb.value),
+                lambda: c.quantize(full.value, W * H + 1, 2, rgb.value),
+                lambda: c.resolve_sums(sums.value, W * H, short.value)):
+        with pytest.raises(api.RtError) as e:
+            bad()
+        assert e.value.code == api.RT_ERR_INVALID and "bytes" in str(e.value)
+    c.render(api.Context.params(W, H, 2, 50, 1, flags=api.RT_FLAG_FIXED_SUMS), sums.value)
+    c.resolve_sums(sums.value, W * H, full.value)
+    c.quantize(full.value, W * H, 2, rgb.value)
+    c.stats()                                                                   # waits for the stream: nothing faulted
+    c.close()
+    for b in (full, short, sums, rgb):
+        hip.hipFree(b)
