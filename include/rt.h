@@ -132,13 +132,17 @@ typedef struct rt_render_params {
     uint32_t flags;              /* RT_FLAG_* */
     int32_t lanes_per_pixel;     /* K = 1,2,4,...,64: a wavefront's tile holds 64/K pixels whose samples its
                                     64 lanes take dynamically; 0 = choose from the frame size */
-    /* Traversal tuning (the image does not depend on either).  A struct whose struct_size ends before
-     * traversal_slice leaves both at their defaults. */
+    /* Traversal tuning (the image does not depend on any of it).  A struct whose struct_size ends before
+     * traversal_slice leaves all of it at the defaults. */
     int32_t traversal_slice;     /* BVH node steps a wavefront spends per trip of its path loop before lanes whose
                                     rays are finished shade and start new rays: 0 = chosen from the tree depth,
                                     -1 = never leave a walk early, n > 0 = n steps */
     int32_t leaf_quorum;         /* time-sliced walk: leaves are tested once (lanes waiting at a leaf) x this
                                     >= lanes still walking; 0 = default (2), -1 = wait for every lane */
+    int32_t stack_lds_entries;   /* time-sliced walk of a tree in HBM: entries of a lane's traversal stack kept in LDS; a
+                                    deeper tree's walk keeps the rest in device memory the context allocates.  0 = default
+                                    (24: what leaves six workgroups per CU), else 2 .. 48.  A struct whose struct_size ends
+                                    before this field leaves it at the default. */
 } rt_render_params;
 
 /* one closest-hit answer (hit_record of sceneobject.h:9-14 plus the object's list position) */

@@ -32,6 +32,8 @@ struct rt_context {
     int bvh_nodes = 0, bvh_depth = 0;
     float build_ms = 0.0f;
     int coarse_nodes = 0;          // nodes the 16-bit grid is too coarse for (any: the tree is walked in its float form)
+    int* stack_spill = nullptr;    // deep trees walked out of HBM: a strip per lane for the stack entries beyond the LDS stack
+    int stack_spill_entries = 0;   // entries per strip
 
     // per-render state
     unsigned long long* counters = nullptr;   // device, rt::kNumCounters
@@ -173,8 +175,10 @@ int choose_lanes_per_pixel(long long pixels, int spp) {
 
 int validate_render(rt_context* ctx, const rt_render_params* p, rt::DRender* rp) {
     if (!ctx) return RT_ERR_INVALID;
-    // two layouts are accepted: the whole struct, or the one that ends before the traversal tuning fields
-    const bool has_tuning = p && p->struct_size == sizeof(rt_render_params);
+    // three layouts are accepted: the whole struct, the one that ends before stack_lds_entries, and the
+    // one that ends before the traversal tuning fields
+    const bool has_stack = p && p->struct_size == sizeof(rt_render_params);
+    const bool has_tuning = has_stack || (p && p->struct_size == offsetof(rt_render_params, stack_lds_entries));
     if (!p || (!has_tuning && p->struct_size != offsetof(rt_render_params, traversal_slice)))
         return fail(ctx, RT_ERR_INVALID, "rt_render_params: null or struct_size mismatch");
     if (!ctx->has_scene) return fail(ctx, RT_ERR_NO_SCENE, "no scene uploaded");
@@ -212,12 +216,27 @@ int validate_render(rt_context* ctx, const rt_render_params* p, rt::DRender* rp)
     if (slice < -1 || quorum < -1) return fail(ctx, RT_ERR_INVALID, "traversal_slice and leaf_quorum must be >= -1");
     rp->slice = slice == 0 ? 0x7fffffff : (slice < 0 ? 0 : slice);      // device side: 0x7fffffff = chosen at launch from the tree depth, 0 = unsliced
     rp->leaf_quorum = quorum == 0 ? -1 : (quorum < 0 ? 0 : quorum);     // device side: -1 = default ratio, 0 = wait for all
+    const int lds_entries = has_stack ? p->stack_lds_entries : 0;
+    if (lds_entries != 0 && (lds_entries < 2 || lds_entries > rt::kMaxStack))
+        return fail(ctx, RT_ERR_INVALID, "stack_lds_entries must be 0 or in [2, 48]");
+    rp->stack_cap = lds_entries == 0 ? rt::kLdsStackCap : lds_entries;
     if ((p->flags & RT_FLAG_FIXED_SUMS) && (p->flags & RT_FLAG_MEAN))
         return fail(ctx, RT_ERR_INVALID, "RT_FLAG_FIXED_SUMS excludes RT_FLAG_MEAN (take the mean in rt_resolve_sums)");
     return RT_OK;
 }
 
 int do_render(rt_context* ctx, const rt::DRender& rp, float4* out_dev) {   // with RT_FLAG_FIXED_SUMS out_dev holds 32 bytes per pixel
+    // a tree in HBM deeper than the LDS stack of its walk: a strip per lane for the rest of the stack
+    // (rt_device.h, kLdsStackCap), grown on demand and kept by the context
+    const int spill_need = (ctx->scene.use_bvh && ctx->scene.qnodes) ? ctx->scene.bvh_depth + 2 - rp.stack_cap : 0;
+    if (spill_need > ctx->stack_spill_entries) {
+        if (ctx->stack_spill) (void)hipFree(ctx->stack_spill);     // (waits for the launches that use it)
+        ctx->stack_spill = nullptr; ctx->stack_spill_entries = 0;
+        RT_HIP(ctx, hipMalloc((void**)&ctx->stack_spill, (size_t)rt::kSpillLanes * spill_need * sizeof(int)));
+        ctx->stack_spill_entries = spill_need;
+    }
+    ctx->scene.stack_spill = ctx->stack_spill;
+    ctx->scene.stack_spill_entries = ctx->stack_spill_entries;
     RT_HIP(ctx, hipMemsetAsync(ctx->counters, 0, rt::kNumCounterSlots * sizeof(unsigned long long), ctx->stream));
     RT_HIP(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
     RT_HIP(ctx, rt::launch_render(ctx->scene, ctx->camera, rp, out_dev, ctx->counters, ctx->stream));
@@ -263,6 +282,7 @@ void rt_destroy(rt_context* ctx) {
     if (ctx->counters) (void)hipFree(ctx->counters);
     if (ctx->staging) (void)hipFree(ctx->staging);
     if (ctx->trace_buf) (void)hipFree(ctx->trace_buf);
+    if (ctx->stack_spill) (void)hipFree(ctx->stack_spill);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
     delete ctx;

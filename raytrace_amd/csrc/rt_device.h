@@ -87,6 +87,8 @@ struct DScene {
     const uint8_t* texels;
     int background;
     float bg[3];
+    int* stack_spill;     // deep trees: per lane of a full launch, the traversal stack entries beyond the LDS stack (see kLdsStackCap), or null
+    int stack_spill_entries;  // entries per lane in stack_spill
 };
 
 struct DCamera {          // camera.h:8-16 after the constructor, single precision
@@ -111,6 +113,8 @@ struct DRender {
     int stack_depth;                        // size of the LDS traversal stack in units of kBlock ints (tree depth + 2 entries per lane; 16-bit entries with the tree in LDS)
     int slice;                              // node steps a wave spends on traversal per trip (0 = no limit, 0x7fffffff = choose at launch)
     int leaf_quorum;                        // time-sliced walk: leaves are tested once (lanes waiting at a leaf) x this >= lanes still walking (0 = wait for all, -1 = default)
+    int stack_cap;                          // most entries the LDS stack of a walk out of HBM may hold before it spills (kLdsStackCap, or the caller's)
+    int stack_entries;                      // entries per lane the LDS stack holds (the walk spills beyond them where the kernel is built for it)
 };
 
 // counters[0] rays, [1] samples, [2] box tests, [3] sphere tests, [4] sphere hits,
@@ -119,6 +123,8 @@ constexpr int kNumCounters = 8;
 constexpr int kNumPhaseClocks = 5;         // extra slots behind the counters (diagnostic build)
 constexpr int kNumCounterSlots = kNumCounters + kNumPhaseClocks + 4;   // + eight 32-bit tile counters of the persistent waves
 constexpr int kNoBvh = 0x7fffffff;
+constexpr int kLdsStackCap = 24;            // LDS stack entries of a walk out of HBM that still leave six workgroups per CU (24 KB + 2 KB of accumulators each)
+constexpr int kSpillLanes = 256 * 6 * 256;  // lanes of the largest grid such a kernel is launched with (256 CUs x 6 workgroups x 256 threads)
 constexpr int kMaxStack = 48;               // deepest BVH the traversal stack holds
 
 struct Hit {              // rt_hit of include/rt.h, device side (same layout)

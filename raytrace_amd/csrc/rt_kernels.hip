@@ -276,6 +276,7 @@ struct GeoGlobal {
     static constexpr bool kPrefetchLeaf = true;
     static constexpr bool kPlaneAddressed = false;
     static constexpr bool kQuant = false;
+    static constexpr bool kDeep = false;
     static constexpr int kDone = kTravDone;
     const float4* nodes; const float4* sph; const int2* info;
     V3 reach;                                                    // largest |coordinate| of the tree's box planes, per axis
@@ -288,14 +289,21 @@ struct GeoGlobal {
 // The tree in HBM as 32-byte nodes (rt_lbvh.h, quantize_nodes): two 16-byte loads per node instead of
 // four.  The walk of a large scene is bound by the L1's tag lookups (the lanes of a wave stand at
 // different nodes, so every 16-byte load is a lookup per lane), not by bytes or arithmetic.
-struct GeoGlobalQ {
+// DEEP: the tree is deeper than the LDS stack the kernel's occupancy leaves room for (kLdsStackCap
+// entries): the entries beyond it live in this lane's strip of a spill array in HBM.  A walk rarely
+// gets there (the stack holds one entry per level at which BOTH children were met), but when it
+// does it must not lose one.
+template <bool DEEP>
+struct GeoGlobalQT {
     static constexpr bool kPrefetchLeaf = true;
     static constexpr bool kPlaneAddressed = false;
     static constexpr bool kQuant = true;
+    static constexpr bool kDeep = DEEP;
     static constexpr int kDone = kTravDone;
     const uint4* qnodes; const float4* sph; const int2* info;
     float lo[3], step[3];
     V3 reach;
+    int* spill;                                                  // this lane's strip (DEEP)
     __device__ __forceinline__ int root_ref(int root) const { return root; }
     // (32-bit byte offset from a uniform base: one shift per step instead of 64-bit address
     // arithmetic; the quantised form is only made for trees of fewer than 2^27 nodes)
@@ -306,6 +314,7 @@ struct GeoGlobalQ {
     __device__ __forceinline__ int obj(int i) const { return info[i].x; }
     __device__ __forceinline__ int mat(int i) const { return info[i].y; }
 };
+using GeoGlobalQ = GeoGlobalQT<false>;
 // The LDS copy of the nodes is laid out for the slab test: 80 bytes per node,
 //   [x: left lo, left hi, left lo, right lo, right hi, right lo][y: the same][z: the same][left ref, right ref]
 // so that the plane a ray enters a child's slab through sits at (axis base + 4 bytes if the
@@ -323,6 +332,7 @@ struct GeoLds {
     static constexpr bool kPrefetchLeaf = false;
     static constexpr bool kPlaneAddressed = true;
     static constexpr bool kQuant = false;
+    static constexpr bool kDeep = false;
     static constexpr int kDone = kTravDone16;                     // what the 16-bit stack's bottom entry reads as
     unsigned node_base;                                          // LDS byte address of node 0
     const float4* sph; const int* objs;                          // both point into LDS
@@ -548,7 +558,7 @@ __device__ __forceinline__ int pop_ref(unsigned top) {
 }
 
 template <bool COUNT, bool SLICED, class G>
-__device__ __forceinline__ void hit_bvh(const G& geo, V3 o, const RayN& rn, Origin from, int* stack, int budget, int quorum,
+__device__ __forceinline__ void hit_bvh(const G& geo, V3 o, const RayN& rn, Origin from, int* stack, int lds_entries, int budget, int quorum,
                                         int& cur, int& sp, Cand& best, Counters& cn) {
     const V3 dh = rn.dh;
     const int self = from.sphere();
@@ -588,6 +598,9 @@ __device__ __forceinline__ void hit_bvh(const G& geo, V3 o, const RayN& rn, Orig
     constexpr int kDone = G::kDone;
     const unsigned bottom = (unsigned)(size_t)(__attribute__((address_space(3))) char*)stack + kStackStride;
     unsigned top = bottom + (unsigned)sp * kStackStride;
+    // (G::kDeep) `top` keeps counting past the end of the LDS stack; entries from `limit` on are in the spill strip
+    unsigned limit = 0u;
+    if constexpr (G::kDeep) limit = bottom + (unsigned)(lds_entries - 1) * kStackStride;
     int wave_steps = 0;
     bool stop = false;
     while (cur != kDone && !stop) {
@@ -639,14 +652,20 @@ __device__ __forceinline__ void hit_bvh(const G& geo, V3 o, const RayN& rn, Orig
             // measured 1 % slower)
             if (hl && hr) {
                 bool left_first = tl <= tr;
-                push_ref<G::kPlaneAddressed>(top, left_first ? right : left);
+                if constexpr (G::kDeep) {
+                    if (top < limit) push_ref<false>(top, left_first ? right : left);
+                    else geo.spill[(top - limit) / kStackStride] = left_first ? right : left;
+                } else {
+                    push_ref<G::kPlaneAddressed>(top, left_first ? right : left);
+                }
                 top += kStackStride;
                 cur = left_first ? left : right;
             } else if (hl || hr) {
                 cur = hl ? left : right;
             } else {
                 top -= kStackStride;
-                cur = pop_ref<G::kPlaneAddressed>(top);
+                if constexpr (G::kDeep) cur = top >= limit ? geo.spill[(top - limit) / kStackStride] : pop_ref<false>(top);
+                else cur = pop_ref<G::kPlaneAddressed>(top);
             }
             if constexpr (SLICED) {
                 waiting += __popcll(__ballot(cur < 0 && cur != kDone));
@@ -665,7 +684,8 @@ __device__ __forceinline__ void hit_bvh(const G& geo, V3 o, const RayN& rn, Orig
             int code = ~cur;
             leaf_spheres<COUNT>(geo, code >> kLeafBits, (code & (kLeafCap - 1)) + 1, o, dh, tn_min, self, best, cn);
             top -= kStackStride;
-            cur = pop_ref<G::kPlaneAddressed>(top);
+            if constexpr (G::kDeep) cur = top >= limit ? geo.spill[(top - limit) / kStackStride] : pop_ref<false>(top);
+            else cur = pop_ref<G::kPlaneAddressed>(top);
         }
     }
     // (a finished walk leaves top one entry below the bottom: its sp is not used again)
@@ -1027,15 +1047,18 @@ __device__ __forceinline__ bool shade(const DScene& sc, const G& geo, const DRen
     return !cont || depth >= rp.max_depth;             // main.cc:13-14: the limit ends in black
 }
 
-template <bool LDS, bool QUANT>
+// QUANT: 0 single-precision nodes, 1 the 32-byte quantised nodes, 2 those with a stack that spills to HBM (deep trees)
+template <bool LDS, int QUANT>
 struct GeoOf { using type = GeoGlobal; };
 template <>
-struct GeoOf<false, true> { using type = GeoGlobalQ; };
-template <bool QUANT>
+struct GeoOf<false, 1> { using type = GeoGlobalQT<false>; };
+template <>
+struct GeoOf<false, 2> { using type = GeoGlobalQT<true>; };
+template <int QUANT>
 struct GeoOf<true, QUANT> { using type = GeoLds; };
 
 // Copies the BVH and the sphere list into LDS (LDS variant) behind `lds`.
-template <bool LDS, bool QUANT>
+template <bool LDS, int QUANT>
 __device__ __forceinline__ typename GeoOf<LDS, QUANT>::type stage_geometry(const DScene& sc, int* lds) {
     if constexpr (LDS) {
         float* nodes = reinterpret_cast<float*>(lds);
@@ -1057,8 +1080,10 @@ __device__ __forceinline__ typename GeoOf<LDS, QUANT>::type stage_geometry(const
         for (int i = sc.n_sph + threadIdx.x; i < sc.n_sph_padded; i += kBlock) { sph[i] = sc.sph[i]; objs[i] = 0; }   // the scan's padding
         GeoLds g = {base, sph, objs, mk(sc.tree_reach[0], sc.tree_reach[1], sc.tree_reach[2])};
         return g;
-    } else if constexpr (QUANT) {
-        GeoGlobalQ g = {sc.qnodes, sc.sph, sc.sph_info, {sc.q_lo[0], sc.q_lo[1], sc.q_lo[2]}, {sc.q_step[0], sc.q_step[1], sc.q_step[2]}, mk(sc.tree_reach[0], sc.tree_reach[1], sc.tree_reach[2])};
+    } else if constexpr (QUANT != 0) {
+        int* strip = nullptr;
+        if constexpr (QUANT == 2) strip = sc.stack_spill + ((size_t)blockIdx.x * kBlock + threadIdx.x) * (size_t)sc.stack_spill_entries;
+        GeoGlobalQT<QUANT == 2> g = {sc.qnodes, sc.sph, sc.sph_info, {sc.q_lo[0], sc.q_lo[1], sc.q_lo[2]}, {sc.q_step[0], sc.q_step[1], sc.q_step[2]}, mk(sc.tree_reach[0], sc.tree_reach[1], sc.tree_reach[2]), strip};
         return g;
     } else {
         GeoGlobal g = {sc.nodes, sc.sph, sc.sph_info, mk(sc.tree_reach[0], sc.tree_reach[1], sc.tree_reach[2])};
@@ -1090,7 +1115,7 @@ __device__ __forceinline__ float from_fixed(unsigned long long q) { return (floa
 // MODE: 0 linear scan, 1 BVH, 2 BVH walked in time slices.  Each combination is a kernel of its
 // own: code that a scene never runs (rects, the scan, the tree walk) still costs the code that
 // does run registers and scheduling freedom when it shares a kernel with it.
-template <bool COUNT, bool LDS, bool PROF, int MODE, bool RECTS, bool QUANT>
+template <bool COUNT, bool LDS, bool PROF, int MODE, bool RECTS, int QUANT>
 __global__ __launch_bounds__(kBlock, MODE == 0 ? RT_WG_PER_CU_SCAN : (LDS ? RT_WG_PER_CU : RT_WG_PER_CU_HBM)) void render_kernel(DScene sc, DCamera cam, DRender rp, float4* __restrict__ out,
                                                         unsigned long long* __restrict__ counters) {
     constexpr bool SLICED = MODE == 2, BVH = MODE != 0;
@@ -1268,7 +1293,7 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? RT_WG_PER_CU_SCAN : (LDS ? RT_W
             }
             if (PROF) { unsigned long long t = clk(); ph[1] += t - tq; tq = t; }
             if constexpr (BVH)
-                if (curq != kDone) hit_bvh<COUNT, SLICED>(geo, o, rn, from, stack, rp.slice, rp.leaf_quorum, curq, spq, cq, cn);
+                if (curq != kDone) hit_bvh<COUNT, SLICED>(geo, o, rn, from, stack, rp.stack_entries, rp.slice, rp.leaf_quorum, curq, spq, cq, cn);
             if (PROF) { unsigned long long t = clk(); ph[2] += t - tq; tq = t; }
             if (curq == kDone) {                       // query finished (else: resumed next trip)
                 if (shade<COUNT, RECTS>(sc, geo, rp, cq, key, depth, refine, rn, o, d, T, L, from, cn)) {
@@ -1304,7 +1329,7 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? RT_WG_PER_CU_SCAN : (LDS ? RT_W
 
 // Closest hit over the whole scene (QUANT: a tree is walked through its 32-byte nodes, as a frame
 // walks a tree that does not fit in LDS).
-template <bool COUNT, bool QUANT>
+template <bool COUNT, int QUANT>
 __device__ __forceinline__ Cand closest_hit(const DScene& sc, V3 o, V3 d, float t_min, int* stack, Counters& cn) {
     Cand best = no_hit();
     RayN rn = normalise(d, t_min);
@@ -1313,13 +1338,13 @@ __device__ __forceinline__ Cand closest_hit(const DScene& sc, V3 o, V3 d, float 
     if (!sc.use_bvh) hit_list<COUNT, false>(sc, nullptr, o, rn, no_origin(), best, cn);
     else if (sc.root != kNoBvh) {
         int cur = sc.root, sp = 0;
-        hit_bvh<COUNT, false>(geo, o, rn, no_origin(), stack, 0, 0, cur, sp, best, cn);
+        hit_bvh<COUNT, false>(geo, o, rn, no_origin(), stack, kMaxStack, 0, 0, cur, sp, best, cn);
     }
     return best;
 }
 
 
-template <bool QUANT>
+template <int QUANT>
 __global__ __launch_bounds__(kBlock) void trace_kernel(DScene sc, const float* __restrict__ rays, int n, float t_min,
                                                        uint32_t flags, Hit* __restrict__ out) {
     __shared__ int s_stack[kMaxStack * kBlock];
@@ -1414,16 +1439,6 @@ hipError_t launch_render(const DScene& sc, const DCamera& cam, const DRender& rp
                         sc.ids_fit_16 &&                  // the LDS copy packs list position and material into one word
                         (sc.use_bvh ? sc.n_sph_padded + 8 < 4096 && (size_t)short_depth * kBlock * sizeof(int) + accum_bytes + geo_bytes <= 40 * 1024
                                     : sc.n_sph_padded <= 32);
-    r.stack_depth = (in_lds && sc.use_bvh) ? short_depth : entries;
-    size_t lds = (size_t)r.stack_depth * kBlock * sizeof(int) + accum_bytes;
-    if (in_lds) lds += geo_bytes;
-    // persistent waves: enough workgroups to fill 256 CUs at the kernel's occupancy, never more
-    // than there are tiles
-    const int wg_per_cu = sc.use_bvh ? (in_lds ? RT_WG_PER_CU : RT_WG_PER_CU_HBM) : RT_WG_PER_CU_SCAN;
-    if (blocks > 256 * wg_per_cu) blocks = 256 * wg_per_cu;
-    const bool count = (rp.flags & 4u) != 0u;
-    const bool prof = (rp.flags & 8u) != 0u;
-    dim3 grid((unsigned)blocks), block(kBlock);
     // Deep trees (large scenes) have a long-tailed traversal length: there a wave spends at most
     // `slice` node steps per trip on traversal and unfinished lanes resume on the next trip.
     // The deeper the tree, the longer the tail of the walk and the shorter the best slice (measured
@@ -1435,10 +1450,29 @@ hipError_t launch_render(const DScene& sc, const DCamera& cam, const DRender& rp
     if (r.leaf_quorum < 0) r.leaf_quorum = in_lds ? 2 : 4;
 
     const bool sliced = sc.use_bvh && r.slice > 0;
+    // A tree in HBM deeper than kLdsStackCap - 2 levels: the LDS stack stops at kLdsStackCap entries (more
+    // would cost a workgroup per CU, the sixth wave per SIMD that hides the fetches) and the rest of a
+    // lane's stack lives in the scene's spill array (only the quantised walk is built that way)
+    const int cap = rp.stack_cap >= 2 ? rp.stack_cap : kLdsStackCap;
+    const bool deep = sliced && !in_lds && entries > cap && sc.stack_spill != nullptr && sc.qnodes != nullptr && (rp.flags & 128u) == 0u &&
+                      entries - cap <= sc.stack_spill_entries;
+    r.stack_depth = (in_lds && sc.use_bvh) ? short_depth : (deep ? cap : entries);
+    r.stack_entries = (in_lds && sc.use_bvh) ? 2 * short_depth : r.stack_depth;
+    size_t lds = (size_t)r.stack_depth * kBlock * sizeof(int) + accum_bytes;
+    if (in_lds) lds += geo_bytes;
+    // persistent waves: enough workgroups to fill 256 CUs at the kernel's occupancy, never more
+    // than there are tiles
+    static_assert(kSpillLanes == 256 * RT_WG_PER_CU_HBM * kBlock, "one spill strip per lane of the largest grid");
+    const int wg_per_cu = sc.use_bvh ? (in_lds ? RT_WG_PER_CU : RT_WG_PER_CU_HBM) : RT_WG_PER_CU_SCAN;
+    if (blocks > 256 * wg_per_cu) blocks = 256 * wg_per_cu;
+    const bool count = (rp.flags & 4u) != 0u;
+    const bool prof = (rp.flags & 8u) != 0u;
+    dim3 grid((unsigned)blocks), block(kBlock);
 #define RT_LAUNCH(...) hipLaunchKernelGGL((render_kernel<__VA_ARGS__>), grid, block, lds, stream, sc, cam, r, out, counters)
     // a tree read from HBM is walked through its 32-byte quantised nodes
     const bool quant = sc.use_bvh && !in_lds && sc.qnodes != nullptr && (rp.flags & 128u) == 0u;
-#define RT_LAUNCH_Q(C, L, P, M, R) do { if (!L && M != 0 && quant) RT_LAUNCH(C, L, P, M, R, (!L && M != 0)); else RT_LAUNCH(C, L, P, M, R, false); } while (0)
+#define RT_LAUNCH_Q(C, L, P, M, R) do { if (!L && M == 2 && quant && deep) RT_LAUNCH(C, L, P, M, R, ((!L && M == 2) ? 2 : 0)); \
+        else if (!L && M != 0 && quant) RT_LAUNCH(C, L, P, M, R, ((!L && M != 0) ? 1 : 0)); else RT_LAUNCH(C, L, P, M, R, 0); } while (0)
 #define RT_LAUNCH_R(C, L, P, M) do { if (sc.n_rects > 0 || sc.has_textures) RT_LAUNCH_Q(C, L, P, M, true); else RT_LAUNCH_Q(C, L, P, M, false); } while (0)
 #define RT_LAUNCH_M(C, P) do { \
         if (!sc.use_bvh) { if (in_lds) RT_LAUNCH_R(C, true, P, 0); else RT_LAUNCH_R(C, false, P, 0); } \
@@ -1460,9 +1494,9 @@ hipError_t launch_trace(const DScene& sc, const float* rays, int n, float t_min,
     if (n <= 0) return hipSuccess;
     // the walk a frame of this scene would use when the tree does not fit in LDS
     if (sc.use_bvh && sc.qnodes != nullptr && (flags & 128u) == 0u)
-        hipLaunchKernelGGL(trace_kernel<true>, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, sc, rays, n, t_min, flags, out);
+        hipLaunchKernelGGL(trace_kernel<1>, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, sc, rays, n, t_min, flags, out);
     else
-        hipLaunchKernelGGL(trace_kernel<false>, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, sc, rays, n, t_min, flags, out);
+        hipLaunchKernelGGL(trace_kernel<0>, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, sc, rays, n, t_min, flags, out);
     return hipGetLastError();
 }
 

@@ -276,6 +276,9 @@ def test_params_layouts_and_tuning_fields(api, rtiow_flat):
     out = np.zeros((H, W, 4), np.float32)
     assert api.lib().rt_render_host(ctx._h, ctypes.byref(p), out.ctypes.data) == api.RT_OK
     assert np.array_equal(out, ref)
+    p.struct_size = api.RenderParams.stack_lds_entries.offset          # the layout with two tuning fields
+    assert api.lib().rt_render_host(ctx._h, ctypes.byref(p), out.ctypes.data) == api.RT_OK
+    assert np.array_equal(out, ref)
     p.struct_size = 40
     assert api.lib().rt_render_host(ctx._h, ctypes.byref(p), out.ctypes.data) == api.RT_ERR_INVALID
     # any slice and quorum: the same frame, the same rays
@@ -464,3 +467,32 @@ def test_quantised_nodes_lose_no_hit_on_a_scene_of_mixed_scales(api, S, offset, 
     else:
         # nodes over spheres far smaller than a step of the grid: the flag changes nothing
         assert 0.05 < coarse < 0.5 and box_q == box_f, (coarse, box_f, box_q)
+
+
+# ---- a traversal stack that does not fit in LDS -------------------------------------------------------------------------------
+
+def test_a_stack_that_spills_out_of_lds_loses_no_node(api, S):
+    """The time-sliced walk of a tree in HBM keeps at most stack_lds_entries entries of a lane's stack
+    in LDS (24 by default: what leaves six workgroups per CU) and the rest in device memory, which a
+    walk reaches only in trees deeper than 22 levels.  With 2, 3 and 5 entries in LDS nearly every push
+    of this 15-level tree goes to device memory: the frame and the ray count must not change, whichever
+    builder made the tree, at full depth and with id-coded emitters (depth 1: a pixel is its closest hit)."""
+    flat = S.stress_flat(20_000)
+    cam = S.stress_camera(1.5).desc()
+    W, H = 240, 160
+    P = api.Context.params
+    for accel in (api.RT_ACCEL_BVH, api.RT_ACCEL_BVH_DEVICE):
+        ctx = api.Context(0)
+        ctx.upload_scene(flat, accel=accel)
+        ctx.set_camera(**cam)
+        assert ctx.stats()["bvh_depth"] >= 13 and ctx.stats()["bvh_coarse_nodes"] == 0
+        for depth, spp in ((50, 4), (1, 2)):
+            ref = ctx.render_host(P(W, H, spp, depth, 5))
+            rays = ctx.stats()["rays"]
+            for entries, sl in ((2, 0), (3, 7), (5, 0), (48, 0)):
+                got = ctx.render_host(P(W, H, spp, depth, 5, stack_lds_entries=entries, traversal_slice=sl))
+                assert np.array_equal(got, ref), (accel, depth, entries)
+                assert ctx.stats()["rays"] == rays
+        with pytest.raises(api.RtError):
+            ctx.render_host(P(W, H, 2, 1, 5, stack_lds_entries=1))
+        ctx.close()

@@ -24,7 +24,8 @@ def test_library_exports_every_declared_symbol():
 def test_struct_sizes_match_header_layout():
     from raytrace_amd import api
     assert C.sizeof(api.Hit) == 44 and api.HIT_DTYPE.itemsize == 44
-    assert C.sizeof(api.RenderParams) == 64 and api.RenderParams.traversal_slice.offset == 56    # the 56-byte layout without the tuning fields is accepted too
+    # (the 56-byte layout without the tuning fields and the 64-byte one without stack_lds_entries are accepted too)
+    assert C.sizeof(api.RenderParams) == 72 and api.RenderParams.traversal_slice.offset == 56 and api.RenderParams.stack_lds_entries.offset == 64
     assert C.sizeof(api.CameraDesc) == 13 * 8
 
 

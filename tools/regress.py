@@ -51,11 +51,11 @@ c.close()
 measure("rtiow, linear scan (scalar loads)", rtiow, RTIOW_CAM, 1920, 1080, 100, accel=api.RT_ACCEL_LIST)
 measure("rtiow, GPU-built tree", rtiow, RTIOW_CAM, 1920, 1080, 100, accel=api.RT_ACCEL_BVH_DEVICE)
 
-cornell = S.flatten(S.cornell_scene(), background=api.RT_BG_SOLID)
+cornell = S.flatten(S.cornell_scene(), background=S.RT_BG_SOLID)
 measure("cornell (scan of 2 spheres from LDS + 6 rects)", cornell, S.cornell_camera(A).desc(), 1920, 1080, 100)
-boxes = S.flatten(S.cornell_boxes_scene(), background=api.RT_BG_SOLID)
+boxes = S.flatten(S.cornell_boxes_scene(), background=S.RT_BG_SOLID)
 measure("cornell with two turned boxes (instance rects)", boxes, S.cornell_camera(A).desc(), 1920, 1080, 100)
-sky = S.flatten(S.skybox_scene(), background=api.RT_BG_SOLID)
+sky = S.flatten(S.skybox_scene(), background=S.RT_BG_SOLID)
 measure("skybox world (image textures, boxes, 125 balls)", sky, S.skybox_camera(A).desc(), 1920, 1080, 100)
 
 for n, (W, H, spp) in ((20_000, (1920, 1080, 64)), (100_000, (1920, 1080, 64)), (1_000_000, (3840, 2160, 16))):
