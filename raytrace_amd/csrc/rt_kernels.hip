@@ -970,7 +970,7 @@ __device__ __forceinline__ bool scatter(const DScene& sc, const DMaterial& m, V3
 // Segment 0 of a sample: its Philox block holds the two pixel jitters (words 0,1) and the first
 // lens-disk attempt (word 2 -> y, word 3 -> x: vec3.h:152 evaluated right to left); further
 // attempts come from the stepped xoshiro128 engine (see Xo).
-__device__ __forceinline__ void camera_ray(const DCamera& cam, const DRender& rp, const Key& k, int i, int j, V3& o, V3& d) {
+__device__ __forceinline__ void camera_ray(const DCamera& cam /* the workgroup's LDS copy */, const DRender& rp, const Key& k, int i, int j, V3& o, V3& d) {
     uint4 w = philox4x32_10(k.pixel, k.sample, 0u, 0u, k.seed_lo, k.seed_hi);
     float s = ((float)i + u01(w.x)) * rp.inv_wm1;
     float t = ((float)j + u01(w.y)) * rp.inv_hm1;
@@ -1136,6 +1136,12 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? RT_WG_PER_CU_SCAN : (LDS ? RT_W
     const float4* staged_list = geo.sph;               // the scan reads it when LDS (else it takes the records through scalar loads)
     (void)staged_list;
     constexpr int kDone = decltype(geo)::kDone;
+    // The camera is read from an LDS copy: as kernel arguments its 19 words sit in scalar registers for
+    // the whole launch (the kernels run out of those and park them in vector-register lanes, which
+    // costs vector instructions on every trip), and a vector operation with a scalar operand issues at
+    // half rate.
+    __shared__ DCamera s_cam;
+    if (threadIdx.x < sizeof(DCamera) / sizeof(float)) reinterpret_cast<float*>(&s_cam)[threadIdx.x] = reinterpret_cast<const float*>(&cam)[threadIdx.x];
     // the entry below every walk's stack (see hit_bvh)
     if constexpr (BVH) {
         if constexpr (LDS) *reinterpret_cast<short*>(stack) = (short)kDone; else *stack = kDone;
@@ -1257,7 +1263,7 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? RT_WG_PER_CU_SCAN : (LDS ? RT_W
                 if (x >= 0) {
                     key.pixel = (uint32_t)(j * rp.width + x);
                     key.sample = (uint32_t)rp.sample_begin + (uint32_t)(u >> logP);
-                    camera_ray(cam, rp, key, x, j, o, d);
+                    camera_ray(s_cam, rp, key, x, j, o, d);
                     T = mk(1.0f, 1.0f, 1.0f);
                     L = mk(0.0f, 0.0f, 0.0f);
                     depth = 0;
