@@ -15,6 +15,16 @@ namespace rt {
 
 __host__ __device__ __forceinline__ uint4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                                         uint32_t k0, uint32_t k1) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // The key is the same in every lane, so the compiler works the ten round keys out once per launch
+    // and keeps them in twenty scalar registers.  The render kernels have none to spare: the keys end
+    // up parked in the lanes of a vector register, and every use is a v_readlane and a wait state.
+    // Behind this barrier they are worked out where they are used instead (scalar adds, which cost the
+    // vector pipes nothing): headline frame -1.9 %, Cornell -0.6 %, 10^6 spheres -1.4 %.  (Kept per
+    // lane in vector registers they gained the sphere-only kernels 0.8 % and cost the kernels that
+    // carry rect and texture code, short of vector registers, 1.6 %.)
+    asm volatile("" : "+s"(k0), "+s"(k1));
+#endif
 #pragma unroll
     for (int r = 0; r < 10; r++) {
         uint64_t p0 = (uint64_t)0xD2511F53u * c0;
