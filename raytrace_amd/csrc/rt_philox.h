@@ -13,6 +13,11 @@
 
 namespace rt {
 
+// XOR3 (device code): the three-operand exclusive-or of a round as one instruction (inline assembly,
+// which ties the register allocator's hands a little): 1 % of the frame for the kernels that have
+// registers to spare, five more spilled registers and 2 % lost for those that do not; the caller
+// chooses.  Same numbers either way.
+template <bool XOR3 = false>
 __host__ __device__ __forceinline__ uint4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                                         uint32_t k0, uint32_t k1) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -31,6 +36,14 @@ __host__ __device__ __forceinline__ uint4 philox4x32_10(uint32_t c0, uint32_t c1
         uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
         uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
         uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (XOR3) {
+            // v_bitop3 with the truth table of a ^ b ^ c (the compiler emits two two-operand
+            // instructions, the second with the scalar key at half rate)
+            asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x96" : "=v"(n0) : "v"((uint32_t)(p1 >> 32)), "v"(c1), "s"(k0));
+            asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x96" : "=v"(n2) : "v"((uint32_t)(p0 >> 32)), "v"(c3), "s"(k1));
+        }
+#endif
         c1 = (uint32_t)p1;
         c3 = (uint32_t)p0;
         c0 = n0;
