@@ -970,9 +970,9 @@ __device__ __forceinline__ bool scatter(const DScene& sc, const DMaterial& m, V3
 // Segment 0 of a sample: its Philox block holds the two pixel jitters (words 0,1) and the first
 // lens-disk attempt (word 2 -> y, word 3 -> x: vec3.h:152 evaluated right to left); further
 // attempts come from the stepped xoshiro128 engine (see Xo).
-template <bool XOR3>
+template <bool XOR3, bool ORDERED>
 __device__ __forceinline__ void camera_ray(const DCamera& cam /* the workgroup's LDS copy */, const DRender& rp, const Key& k, int i, int j, V3& o, V3& d) {
-    uint4 w = philox4x32_10<XOR3>(k.pixel, k.sample, 0u, 0u, k.seed_lo, k.seed_hi);
+    uint4 w = philox4x32_10<XOR3, ORDERED>(k.pixel, k.sample, 0u, 0u, k.seed_lo, k.seed_hi);
     float s = ((float)i + u01(w.x)) * rp.inv_wm1;
     float t = ((float)j + u01(w.y)) * rp.inv_hm1;
     V3 offset = mk(0.0f, 0.0f, 0.0f);
@@ -1030,7 +1030,9 @@ __device__ __forceinline__ bool shade(const DScene& sc, const G& geo, const DRen
     DMaterial m = sc.mats[mat];
     if (!RECTS) m.tex = -1;        // a kernel without the rect code serves scenes without textures too: none of that code is kept
     // one Philox block per scatter segment, shared by whichever material consumes it
-    const uint4 w = philox4x32_10<!RECTS>(key.pixel, key.sample, (uint32_t)depth, 0u, key.seed_lo, key.seed_hi);   // (the sphere-only kernels have the registers: rt_philox.h)
+    // (the sphere-only kernels have the registers for the fused exclusive-or; the kernels that read
+    // their geometry from HBM want their loads kept behind the block: rt_philox.h)
+    const uint4 w = philox4x32_10<!RECTS, !G::kPlaneAddressed>(key.pixel, key.sample, (uint32_t)depth, 0u, key.seed_lo, key.seed_hi);
     Rec r = make_record<RECTS>(sc, c, o, d, rn.inv_len, refine, m.tex >= 0, s64, mat);
     V3 att, sd, em;
     if (COUNT) cn.shade++;
@@ -1264,7 +1266,7 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? RT_WG_PER_CU_SCAN : (LDS ? RT_W
                 if (x >= 0) {
                     key.pixel = (uint32_t)(j * rp.width + x);
                     key.sample = (uint32_t)rp.sample_begin + (uint32_t)(u >> logP);
-                    camera_ray<!RECTS>(s_cam, rp, key, x, j, o, d);
+                    camera_ray<!RECTS, !LDS>(s_cam, rp, key, x, j, o, d);
                     T = mk(1.0f, 1.0f, 1.0f);
                     L = mk(0.0f, 0.0f, 0.0f);
                     depth = 0;

@@ -13,11 +13,12 @@
 
 namespace rt {
 
-// XOR3 (device code): the three-operand exclusive-or of a round as one instruction (inline assembly,
-// which ties the register allocator's hands a little): 1 % of the frame for the kernels that have
-// registers to spare, five more spilled registers and 2 % lost for those that do not; the caller
-// chooses.  Same numbers either way.
-template <bool XOR3 = false>
+// Device code only, same numbers whichever way:
+// XOR3: the three-operand exclusive-or of a round as one instruction (inline assembly, which ties
+// the register allocator's hands a little): 1 % of the frame for the kernels that have registers to
+// spare, five more spilled registers and 2 % lost for those that do not.
+// ORDERED: see the barrier below.  The caller chooses both.
+template <bool XOR3 = false, bool ORDERED = false>
 __host__ __device__ __forceinline__ uint4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                                         uint32_t k0, uint32_t k1) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -28,7 +29,15 @@ __host__ __device__ __forceinline__ uint4 philox4x32_10(uint32_t c0, uint32_t c1
     // vector pipes nothing): headline frame -1.9 %, Cornell -0.6 %, 10^6 spheres -1.4 %.  (Kept per
     // lane in vector registers they gained the sphere-only kernels 0.8 % and cost the kernels that
     // carry rect and texture code, short of vector registers, 1.6 %.)
-    asm volatile("" : "+s"(k0), "+s"(k1));
+    // The barrier comes in two strengths.  A `volatile` statement counts as a possible write to
+    // memory: no load moves across it, and every load of a scene record after it goes through the
+    // vector memory path instead of a scalar load.  That costs a room of turned boxes (twelve rect
+    // and transform records per ray) 20 % and Cornell 2.4 %, and it GAINS the walk out of HBM 2.6 %
+    // (10^6 spheres; the shading loads stay behind the block instead of being live across it).  The
+    // plain statement with the counter as a dummy input stays inside the path loop all the same
+    // (its result depends on the counter) and leaves the loads alone.
+    if constexpr (ORDERED) asm volatile("" : "+s"(k0), "+s"(k1));
+    else asm("" : "+s"(k0), "+s"(k1) : "v"(c0));
 #endif
 #pragma unroll
     for (int r = 0; r < 10; r++) {
