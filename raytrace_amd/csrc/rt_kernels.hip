@@ -1030,9 +1030,10 @@ __device__ __forceinline__ bool shade(const DScene& sc, const G& geo, const DRen
     DMaterial m = sc.mats[mat];
     if (!RECTS) m.tex = -1;        // a kernel without the rect code serves scenes without textures too: none of that code is kept
     // one Philox block per scatter segment, shared by whichever material consumes it
-    // (the sphere-only kernels have the registers for the fused exclusive-or; the kernels that read
-    // their geometry from HBM want their loads kept behind the block: rt_philox.h)
-    const uint4 w = philox4x32_10<!RECTS, !G::kPlaneAddressed>(key.pixel, key.sample, (uint32_t)depth, 0u, key.seed_lo, key.seed_hi);
+    // (the fused exclusive-or wherever the geometry is in LDS or the kernel carries no rect and texture
+    // code: the walk out of HBM with that code is the one kernel it costs registers it does not have;
+    // the kernels that read their geometry from HBM want their loads kept behind the block: rt_philox.h)
+    const uint4 w = philox4x32_10<!RECTS || G::kPlaneAddressed, !G::kPlaneAddressed>(key.pixel, key.sample, (uint32_t)depth, 0u, key.seed_lo, key.seed_hi);
     Rec r = make_record<RECTS>(sc, c, o, d, rn.inv_len, refine, m.tex >= 0, s64, mat);
     V3 att, sd, em;
     if (COUNT) cn.shade++;
@@ -1266,7 +1267,7 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? RT_WG_PER_CU_SCAN : (LDS ? RT_W
                 if (x >= 0) {
                     key.pixel = (uint32_t)(j * rp.width + x);
                     key.sample = (uint32_t)rp.sample_begin + (uint32_t)(u >> logP);
-                    camera_ray<!RECTS, !LDS>(s_cam, rp, key, x, j, o, d);
+                    camera_ray<!RECTS || LDS, !LDS>(s_cam, rp, key, x, j, o, d);
                     T = mk(1.0f, 1.0f, 1.0f);
                     L = mk(0.0f, 0.0f, 0.0f);
                     depth = 0;

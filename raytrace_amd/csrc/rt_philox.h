@@ -15,8 +15,9 @@ namespace rt {
 
 // Device code only, same numbers whichever way:
 // XOR3: the three-operand exclusive-or of a round as one instruction (inline assembly, which ties
-// the register allocator's hands a little): 1 % of the frame for the kernels that have registers to
-// spare, five more spilled registers and 2 % lost for those that do not.
+// the register allocator's hands a little): 1 - 1.6 % of the frame for most kernels, five more
+// spilled registers and 1 - 2 % lost for the one shortest of them (the walk out of HBM that also
+// carries rect and texture code).
 // ORDERED: see the barrier below.  The caller chooses both.
 template <bool XOR3 = false, bool ORDERED = false>
 __host__ __device__ __forceinline__ uint4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
