@@ -1451,10 +1451,12 @@ hipError_t launch_render(const DScene& sc, const DCamera& cam, const DRender& rp
                                     : sc.n_sph_padded <= 32);
     // Deep trees (large scenes) have a long-tailed traversal length: there a wave spends at most
     // `slice` node steps per trip on traversal and unfinished lanes resume on the next trip.
-    // The deeper the tree, the longer the tail of the walk and the shorter the best slice (measured
-    // on slabs of 2 x 10^4, 10^5 and 10^6 spheres, 15 / 17 / 21 levels: best at about 128, 64, 48
-    // steps; against the 32 used before: -8 %, -7 %, -2 % of the frame).  The image does not depend on it.
-    if (r.slice == 0x7fffffff) r.slice = sc.bvh_depth > 12 ? (sc.bvh_depth >= 20 ? 48 : (sc.bvh_depth >= 16 ? 64 : 128)) : 0;
+    // The deeper the tree, the longer the tail of the walk and the shorter the best slice (slabs of
+    // 10^5 and 10^6 spheres, 18 and 22 levels: best at about 64 and 48 steps).  Up to 16 levels the
+    // plain walk is as fast or faster with today's kernels (2 x 10^4 spheres, 15 levels: 9.8 ms
+    // against 10.7 at the best slice; 3.5 x 10^4, 16 levels: 13.6 against 14.0; 5 x 10^4, 16 levels:
+    // 16.7 against 16.4; 7 x 10^4, 18 levels: 21.9 against 19.9).  The image does not depend on it.
+    if (r.slice == 0x7fffffff) r.slice = sc.bvh_depth > 16 ? (sc.bvh_depth >= 20 ? 48 : 64) : 0;
     // (with six waves per SIMD on a tree in HBM the walkers may be a little fewer before the wave
     // turns to its leaves: 10^6 spheres -2.5 % against a ratio of 2)
     if (r.leaf_quorum < 0) r.leaf_quorum = in_lds ? 2 : 4;

@@ -1,5 +1,5 @@
 """Frame time of the stress scene (tree walked out of HBM) by traversal slice and leaf quorum
-(rt_render_params.traversal_slice, leaf_quorum).  usage: python tools/slice_probe.py [spp]"""
+(rt_render_params.traversal_slice, leaf_quorum).  usage: python tools/slice_probe.py [spp] [n_spheres] [width height]"""
 import os
 import sys
 
@@ -8,12 +8,14 @@ import torch                                      # noqa: E402
 from raytrace_amd import api, scene as S          # noqa: E402
 
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000
+W, H = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (3840, 2160)
 ctx = api.Context(0)
-ctx.upload_scene(S.stress_flat(1_000_000), accel=api.RT_ACCEL_BVH)
+ctx.upload_scene(S.stress_flat(n), accel=api.RT_ACCEL_BVH)
 ctx.set_camera(**S.stress_camera(16 / 9).desc())
-W, H = 3840, 2160
 buf = torch.zeros((H, W, 4), device="cuda")
-cases = [(0, 0), (-1, 0)] + [(sl, q) for sl in (16, 24, 32, 48, 64, 96) for q in (1, 2, 3, 4)] + [(48, -1), (48, 8)]
+print(f"{n} spheres, depth {ctx.stats()['bvh_depth']}, {W}x{H}@{spp}", flush=True)
+cases = [(0, 0), (-1, 0)] + [(sl, q) for sl in (32, 48, 64, 96, 128, 192, 256) for q in (2, 4, 6)]
 for sl, q in cases:
     best = None
     for _ in range(2):
