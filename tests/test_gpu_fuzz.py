@@ -72,7 +72,7 @@ def _random_scene(S, rng):
 # |unit direction|^2 - 1 (1e-7) times the squared distance is as large as the discriminant
 # 18788 has a checker texture that changes sign across a rect's plane within an ulp of the plane's
 # coordinate
-_KEPT_SEEDS = [2161, 5899, 14114, 18788, 56104, 343970, 345337]   # 56104: a root 6.6e-7 above t_min; 343970: one 1 % above it, 2000 from the origin; 345337: no ray meets anything
+_KEPT_SEEDS = [2161, 5899, 14114, 18788, 56104, 343970, 345337, 545253]   # 56104: a root 6.6e-7 above t_min; 343970: one 1 % above it, 2000 from the origin; 345337: no ray meets anything; 545253: a normal at cos 1.6e-3
 _N_SEEDS = int(__import__("os").environ.get("RT_FUZZ_SEEDS", "40"))
 _FIRST_SEED = int(__import__("os").environ.get("RT_FUZZ_FIRST", "0"))          # long runs by hand, in parts
 
@@ -118,7 +118,10 @@ def test_random_scene(seed, oracle):
             worst = np.where(ok)[0][int(np.argmax(rel))]
             assert rel.max() <= 1e-5, (accel, float(rel.max()), int(worst), float(hits["t"][worst]), float(want["t"][worst]),
                                        int(want["id"][worst]), rays[worst].tolist(), float(scale), np.asarray(offset).tolist())
-            assert np.abs(hits["n"][ok] - want["n"][ok]).max() <= 1e-5
+            # a normal moves by (shift of the hit point) / radius, and the hit point of a grazing ray by
+            # (shift of the surface: 1e-7 of its coordinates, the rounding of the records) / cos
+            # (scene 545253 of the generator: cos 1.6e-3, t off by 1.4e-6 of itself, the normal by 6.7e-5)
+            assert (np.abs(hits["n"][ok] - want["n"][ok]).max(axis=1) <= 1e-5 + 2e-7 / cos[ok]).all()
             assert np.array_equal(hits["front_face"][ok], want["front"][ok])
         img = ctx.render_host(api.Context.params(W, H, spp, 50, 77 + seed))
         st = ctx.stats()
@@ -220,7 +223,7 @@ def test_random_sphere_field(seed, oracle):
         ok = ~bad & (want["id"] >= 0) & (cos > 1e-3)
         rel = np.abs(hits["t"][ok] - want["t"][ok]) / np.abs(want["t"][ok])
         assert rel.max() <= 1e-5, (accel, float(rel.max()))
-        assert np.abs(hits["n"][ok] - want["n"][ok]).max() <= 1e-5
+        assert (np.abs(hits["n"][ok] - want["n"][ok]).max(axis=1) <= 1e-5 + 2e-7 / cos[ok]).all()   # (grazing rays: as in test_random_scene)
         img = ctx.render_host(api.Context.params(W, H, spp, depth, 9 + seed))
         st = ctx.stats()
         if accel == api.RT_ACCEL_BVH:
