@@ -128,10 +128,11 @@ def test_random_scene(seed, oracle):
         if accel != api.RT_ACCEL_LIST:
             # the same tree read from HBM instead of LDS, and walked in time slices (what scenes too
             # large for LDS and trees deeper than 12 levels get): the same frame, the same ray count
-            for flags, slice_steps in ((api.RT_FLAG_NO_LDS_SCENE, 0), (0, 3), (api.RT_FLAG_NO_LDS_SCENE, 5),
-                                        (api.RT_FLAG_NO_LDS_SCENE | api.RT_FLAG_FLOAT_NODES, 0)):
-                other = ctx.render_host(api.Context.params(W, H, spp, 50, 77 + seed, flags=flags, traversal_slice=slice_steps))
-                assert np.array_equal(other, img), (accel, flags, slice_steps)
+            # (and with two entries of each lane's stack in LDS, the rest in device memory)
+            for flags, slice_steps, entries in ((api.RT_FLAG_NO_LDS_SCENE, 0, 0), (0, 3, 0), (api.RT_FLAG_NO_LDS_SCENE, 5, 0),
+                                                 (api.RT_FLAG_NO_LDS_SCENE | api.RT_FLAG_FLOAT_NODES, 0, 0), (api.RT_FLAG_NO_LDS_SCENE, 7, 2)):
+                other = ctx.render_host(api.Context.params(W, H, spp, 50, 77 + seed, flags=flags, traversal_slice=slice_steps, stack_lds_entries=entries))
+                assert np.array_equal(other, img), (accel, flags, slice_steps, entries)
                 assert ctx.stats()["rays"] == st["rays"]
         if accel == api.RT_ACCEL_BVH:
             # three interleaved shards of 4-row tiles, another tile shape: the same bits
@@ -228,6 +229,9 @@ def test_random_sphere_field(seed, oracle):
         st = ctx.stats()
         if accel == api.RT_ACCEL_BVH:
             assert np.array_equal(ctx.render_host(api.Context.params(W, H, spp, depth, 9 + seed, flags=api.RT_FLAG_NO_LDS_SCENE)), img)
+            # time-sliced, with three entries of each lane's stack in LDS and the rest in device memory
+            assert np.array_equal(ctx.render_host(api.Context.params(W, H, spp, depth, 9 + seed, flags=api.RT_FLAG_NO_LDS_SCENE, traversal_slice=24,
+                                                                      stack_lds_entries=3)), img)
         ctx.close()
         if first is None:
             first = img
