@@ -5,6 +5,7 @@
 
 `render_sequence` writes P3 text like the reference (cuda/main.cu:358-383, with color.h's clamp),
 binary P6, or PNG directly, which replaces cuda/output/convert.py (ImageMagick per file).
+`render_pairs` writes the low / high sample-count pair of every frame that loop is laid out for.
 `encode_video` is cuda/output/generate_video.py: the same ffmpeg command line, run only when
 ffmpeg exists.  With several ranks (one process per GPU) frames are dealt round-robin: frames are
 independent, so there is nothing to exchange.
@@ -102,6 +103,65 @@ def render_sequence(ctx, cam: S.camera, frames, width: int, height: int, spp: in
             pending = None
     if pending is not None:
         finish(*pending)
+    return done
+
+
+def render_pairs(ctx, cam: S.camera, frames, width: int, height: int, low_spp: int, high_spp: int, out_dir: str | None,
+                 max_depth: int = 25, seed: int = 1, fmt: str = "p3", rank: int = 0, world: int = 1, first_frame: int = 0):
+    """The reference's "low-high samples of each image" loop (cuda/main.cu:557-583: image_<frame>_low at
+    low_num_samples, image_<frame>_high at high_num_samples, main.cu:445-446, :569, :575) for the cost of
+    the high frames alone.  Samples are keyed by their index, so the low frame is the first low_spp
+    samples of the high one: each frame is rendered as two windows of samples into integer sums, the low
+    file is written from the first window and the high file from the two windows added (integer sums
+    add exactly: the high file is bit for bit the one a single render at high_spp writes).
+    Returns [(frame, rays, kernel_ms)] with both windows counted."""
+    import torch
+
+    from . import api
+
+    if not 1 <= low_spp < high_spp:
+        raise ValueError("need 1 <= low_spp < high_spp")
+    if fmt not in ("p3", "p6", "png"):
+        raise ValueError(f"unknown format {fmt!r}")
+    dev = f"cuda:{ctx.device}"
+    sums = [torch.zeros((height, width, 4), dtype=torch.int64, device=dev) for _ in range(2)]   # 32.32 sums as their bit patterns
+    fb = torch.zeros((height, width, 4), dtype=torch.float32, device=dev)
+    rgb = torch.zeros((height, width, 3), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    done = []
+
+    def write(frame, quality, spp, sums_t):
+        ctx.resolve_sums(sums_t.data_ptr(), width * height, fb.data_ptr())
+        ctx.quantize(fb.data_ptr(), width * height, spp, rgb.data_ptr())
+        ctx.stats()                                             # waits for the context's stream
+        img = rgb.cpu().numpy()
+        if out_dir is not None:
+            path = frame_path(out_dir, frame, fmt, quality)
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            if fmt == "p3":
+                ppm.write_p3(path, img)
+            elif fmt == "p6":
+                ppm.write_p6(path, img)
+            else:
+                with open(path, "wb") as f:
+                    f.write(png_bytes(img))
+
+    for frame in range(first_frame + frames):
+        S.update_scene(cam, frame)                              # cuda/main.cu:564
+        if frame < first_frame or frame % world != rank:
+            continue
+        ctx.set_camera(**cam.desc())
+        rays, ms = 0, 0.0
+        for k, (begin, n) in enumerate(((0, low_spp), (low_spp, high_spp - low_spp))):
+            ctx.render(api.Context.params(width, height, n, max_depth, seed=seed + frame, sample_begin=begin,
+                                          flags=api.RT_FLAG_FIXED_SUMS), sums[k].data_ptr())
+            st = ctx.stats()
+            rays, ms = rays + st["rays"], ms + st["kernel_ms"]
+        write(frame, "low", low_spp, sums[0])
+        sums[1] += sums[0]                                      # (on torch's stream; the context's is idle: write() waited)
+        torch.cuda.synchronize()
+        write(frame, "high", high_spp, sums[1])
+        done.append((frame, rays, ms))
     return done
 
 

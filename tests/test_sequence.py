@@ -67,3 +67,29 @@ def test_sequence_frames_on_gpu(tmp_path, oracle):
         assert open(sequence.frame_path(str(out2), f, "p3")).read() == open(sequence.frame_path(str(tmp_path), f, "p3")).read()
     other.close()
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_low_high_pairs_are_the_files_of_two_sequences(tmp_path):
+    """The low / high sample-count pair of every frame (cuda/main.cu:557-583, 1 and 20 samples there),
+    rendered as two windows of the high frame's samples: the low file is the one a sequence at low_spp
+    writes, the high file the one a sequence at high_spp writes, and the rays add up to the high
+    sequence's."""
+    from raytrace_amd import api, scene as S, sequence
+    ctx = api.Context(0)
+    ctx.upload_scene(S.flatten(S.rtiow_scene()))
+    W, H, low, high = 96, 54, 1, 6
+    pairs = sequence.render_pairs(ctx, S.rtiow_camera(W / H), 2, W, H, low, high, str(tmp_path / "pairs"), first_frame=1)
+    lo = sequence.render_sequence(ctx, S.rtiow_camera(W / H), 2, W, H, low, str(tmp_path / "lo"), quality="low", first_frame=1)
+    hi = sequence.render_sequence(ctx, S.rtiow_camera(W / H), 2, W, H, high, str(tmp_path / "hi"), quality="high", first_frame=1)
+    assert [d[0] for d in pairs] == [1, 2]
+    assert [d[1] for d in pairs] == [d[1] for d in hi]
+    for f in (1, 2):
+        for quality, single in (("low", "lo"), ("high", "hi")):
+            got = open(sequence.frame_path(str(tmp_path / "pairs"), f, "p3", quality)).read()
+            assert got == open(sequence.frame_path(str(tmp_path / single), f, "p3", quality)).read(), (f, quality)
+    assert open(sequence.frame_path(str(tmp_path / "pairs"), 1, "p3", "low")).read() != \
+        open(sequence.frame_path(str(tmp_path / "pairs"), 1, "p3", "high")).read()
+    with pytest.raises(ValueError):
+        sequence.render_pairs(ctx, S.rtiow_camera(W / H), 1, W, H, 4, 4, None)
+    ctx.close()
