@@ -138,7 +138,8 @@ typedef struct rt_render_params {
                                     rays are finished shade and start new rays: 0 = chosen from the tree depth,
                                     -1 = never leave a walk early, n > 0 = n steps */
     int32_t leaf_quorum;         /* time-sliced walk: leaves are tested once (lanes waiting at a leaf) x this
-                                    >= lanes still walking; 0 = default (2), -1 = wait for every lane */
+                                    >= lanes still walking; 0 = default (2 with the tree in LDS, 4 with it in
+                                    device memory), -1 = wait for every lane */
     int32_t stack_lds_entries;   /* time-sliced walk of a tree in HBM: entries of a lane's traversal stack kept in LDS; a
                                     deeper tree's walk keeps the rest in device memory the context allocates.  0 = default
                                     (24: what leaves six workgroups per CU), else 2 .. 48.  A struct whose struct_size ends

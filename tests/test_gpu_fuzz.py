@@ -127,7 +127,7 @@ def test_random_scene(seed, oracle):
         st = ctx.stats()
         if accel != api.RT_ACCEL_LIST:
             # the same tree read from HBM instead of LDS, and walked in time slices (what scenes too
-            # large for LDS and trees deeper than 12 levels get): the same frame, the same ray count
+            # large for LDS and trees deeper than 16 levels get): the same frame, the same ray count
             # (and with two entries of each lane's stack in LDS, the rest in device memory)
             for flags, slice_steps, entries in ((api.RT_FLAG_NO_LDS_SCENE, 0, 0), (0, 3, 0), (api.RT_FLAG_NO_LDS_SCENE, 5, 0),
                                                  (api.RT_FLAG_NO_LDS_SCENE | api.RT_FLAG_FLOAT_NODES, 0, 0), (api.RT_FLAG_NO_LDS_SCENE, 7, 2)):
