@@ -136,7 +136,7 @@ typedef struct rt_render_params {
      * traversal_slice leaves all of it at the defaults. */
     int32_t traversal_slice;     /* BVH node steps a wavefront spends per trip of its path loop before lanes whose
                                     rays are finished shade and start new rays: 0 = chosen from the tree depth,
-                                    -1 = never leave a walk early, n > 0 = n steps */
+                                    -1 = never leave a walk early, n > 0 = n steps (at most 65534) */
     int32_t leaf_quorum;         /* time-sliced walk: leaves are tested once (lanes waiting at a leaf) x this
                                     >= lanes still walking; 0 = default (2 with the tree in LDS, 4 with it in
                                     device memory), -1 = wait for every lane */
@@ -144,6 +144,11 @@ typedef struct rt_render_params {
                                     deeper tree's walk keeps the rest in device memory the context allocates.  0 = default
                                     (24: what leaves six workgroups per CU), else 2 .. 48.  A struct whose struct_size ends
                                     before this field leaves it at the default. */
+    int32_t traversal_exit_share; /* time-sliced walk: the wavefront also leaves the walk as soon as the lanes whose walk is
+                                    unfinished are no more than this many 128ths of the lanes that came in with one
+                                    (finished lanes then shade and start new rays while most of them are free): 0 = default
+                                    (64: half), -1 = off, else 1 .. 128.  Read with stack_lds_entries (it fills what was
+                                    padding behind it: zero the struct). */
 } rt_render_params;
 
 /* one closest-hit answer (hit_record of sceneobject.h:9-14 plus the object's list position) */

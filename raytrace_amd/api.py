@@ -54,7 +54,7 @@ class RenderParams(C.Structure):
                 ("seed", C.c_uint64), ("tile_rows", C.c_int32), ("tile_first", C.c_int32),
                 ("tile_step", C.c_int32), ("t_min", C.c_float), ("flags", C.c_uint32),
                 ("lanes_per_pixel", C.c_int32), ("traversal_slice", C.c_int32), ("leaf_quorum", C.c_int32),
-                ("stack_lds_entries", C.c_int32)]
+                ("stack_lds_entries", C.c_int32), ("traversal_exit_share", C.c_int32)]
 
 
 class Hit(C.Structure):
@@ -239,7 +239,7 @@ class Context:
 
     @staticmethod
     def params(width, height, spp, max_depth=50, seed=1, sample_begin=0, tiles=(0, 0, 0), t_min=0.0,
-               flags=0, lanes_per_pixel=0, traversal_slice=0, leaf_quorum=0, stack_lds_entries=0):
+               flags=0, lanes_per_pixel=0, traversal_slice=0, leaf_quorum=0, stack_lds_entries=0, traversal_exit_share=0):
         p = RenderParams()
         p.struct_size = C.sizeof(RenderParams)
         p.width, p.height, p.spp, p.sample_begin, p.max_depth = width, height, spp, sample_begin, max_depth
@@ -247,6 +247,7 @@ class Context:
         p.tile_rows, p.tile_first, p.tile_step = tiles
         p.t_min, p.flags, p.lanes_per_pixel = t_min, flags, lanes_per_pixel
         p.traversal_slice, p.leaf_quorum, p.stack_lds_entries = traversal_slice, leaf_quorum, stack_lds_entries
+        p.traversal_exit_share = traversal_exit_share
         return p
 
     @staticmethod

@@ -214,7 +214,10 @@ int validate_render(rt_context* ctx, const rt_render_params* p, rt::DRender* rp)
     rp->inv_hm1 = (float)(1.0 / (double)(p->height - 1));
     const int slice = has_tuning ? p->traversal_slice : 0, quorum = has_tuning ? p->leaf_quorum : 0;
     if (slice < -1 || quorum < -1) return fail(ctx, RT_ERR_INVALID, "traversal_slice and leaf_quorum must be >= -1");
-    rp->slice = slice == 0 ? 0x7fffffff : (slice < 0 ? 0 : slice);      // device side: 0x7fffffff = chosen at launch from the tree depth, 0 = unsliced
+    const int share = has_stack ? p->traversal_exit_share : 0;
+    if (share < -1 || share > 128) return fail(ctx, RT_ERR_INVALID, "traversal_exit_share must be -1, 0 or in [1, 128]");
+    // device side: steps in the low 16 bits (0xffff = chosen at launch from the tree depth, 0 = unsliced), exit share above them
+    rp->slice = (slice == 0 ? 0xffff : (slice < 0 ? 0 : (slice > 65534 ? 65534 : slice))) | ((share == 0 ? rt::kExitShare : (share < 0 ? 0 : share)) << 16);
     rp->leaf_quorum = quorum == 0 ? -1 : (quorum < 0 ? 0 : quorum);     // device side: -1 = default ratio, 0 = wait for all
     const int lds_entries = has_stack ? p->stack_lds_entries : 0;
     if (lds_entries != 0 && (lds_entries < 2 || lds_entries > rt::kMaxStack))

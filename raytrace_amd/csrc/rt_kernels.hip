@@ -603,6 +603,11 @@ __device__ __forceinline__ void hit_bvh(const G& geo, V3 o, const RayN& rn, Orig
     if constexpr (G::kDeep) limit = bottom + (unsigned)(lds_entries - 1) * kStackStride;
     int wave_steps = 0;
     bool stop = false;
+    // (SLICED) budget = steps | share << 16: the wave also leaves the walk as soon as the lanes whose walk
+    // is unfinished are no more than share / 128 of the lanes that came in
+    const int exit_ratio = SLICED ? budget >> 16 : 0;
+    if constexpr (SLICED) budget &= 0xffff;
+    const int entered = SLICED ? __popcll(__ballot(true)) : 0;
     while (cur != kDone && !stop) {
         // Deep trees: a lane meets a leaf every seven or eight node steps, and waiting until all 64
         // lanes stand on one leaves most of them idle for most of the walk.  The wave therefore
@@ -669,14 +674,13 @@ __device__ __forceinline__ void hit_bvh(const G& geo, V3 o, const RayN& rn, Orig
             }
             if constexpr (SLICED) {
                 waiting += __popcll(__ballot(cur < 0 && cur != kDone));
-                leave = waiting * quorum >= __popcll(__ballot(cur >= 0));
-            }
-            if constexpr (SLICED) {
+                const int walking = __popcll(__ballot(cur >= 0));
+                leave = waiting * quorum >= walking;
                 // the count is taken from the first active lane; a lane that sat out some steps at
                 // a leaf brings an older count back when it becomes that lane, so a slice lasts at
                 // least `budget` steps and about twice that in practice (measured 66 for 32)
                 wave_steps = __builtin_amdgcn_readfirstlane(wave_steps) + 1;
-                stop = wave_steps >= budget;
+                stop = wave_steps >= budget || (walking + waiting) * 128 <= entered * exit_ratio;
             }
         }
         if (cur < 0 && cur != kDone) {
@@ -1450,13 +1454,19 @@ hipError_t launch_render(const DScene& sc, const DCamera& cam, const DRender& rp
                         (sc.use_bvh ? sc.n_sph_padded + 8 < 4096 && (size_t)short_depth * kBlock * sizeof(int) + accum_bytes + geo_bytes <= 40 * 1024
                                     : sc.n_sph_padded <= 32);
     // Deep trees (large scenes) have a long-tailed traversal length: there a wave spends at most
-    // `slice` node steps per trip on traversal and unfinished lanes resume on the next trip.
-    // The deeper the tree, the longer the tail of the walk and the shorter the best slice (slabs of
-    // 10^5 and 10^6 spheres, 18 and 22 levels: best at about 64 and 48 steps).  Up to 16 levels the
-    // plain walk is as fast or faster with today's kernels (2 x 10^4 spheres, 15 levels: 9.8 ms
-    // against 10.7 at the best slice; 3.5 x 10^4, 16 levels: 13.6 against 14.0; 5 x 10^4, 16 levels:
-    // 16.7 against 16.4; 7 x 10^4, 18 levels: 21.9 against 19.9).  The image does not depend on it.
-    if (r.slice == 0x7fffffff) r.slice = sc.bvh_depth > 16 ? (sc.bvh_depth >= 20 ? 48 : 64) : 0;
+    // `slice` node steps per trip on traversal, leaves earlier once half the lanes that came in
+    // have finished their walk (the exit share: those lanes then shade and start new rays together,
+    // at a utilisation a fixed budget alone does not give them), and unfinished lanes resume on the
+    // next trip.  Slabs of 10^5 and 10^6 spheres (18 and 22 levels): 23.3 and 76.8 ms with the
+    // share against 24.9 and 79.8 with the best budget alone; 64 to 128 steps then measure alike.
+    // Up to 16 levels the plain walk is as fast or faster (2 x 10^4 spheres, 15 levels: 9.8 ms
+    // against 10.9; 3.5 x 10^4, 16 levels: 13.7 against 14.0; 5 x 10^4, 16 levels: 16.7 against
+    // 16.4; 7 x 10^4, 18 levels: 22.1 against 19.3).  The image does not depend on it.
+    {
+        int steps = r.slice & 0xffff;
+        if (steps == 0xffff) steps = sc.bvh_depth > 16 ? 64 : 0;
+        r.slice = steps > 0 ? (steps | (r.slice & ~0xffff)) : 0;
+    }
     // (with six waves per SIMD on a tree in HBM the walkers may be a little fewer before the wave
     // turns to its leaves: 10^6 spheres -2.5 % against a ratio of 2)
     if (r.leaf_quorum < 0) r.leaf_quorum = in_lds ? 2 : 4;

@@ -129,10 +129,13 @@ def test_random_scene(seed, oracle):
             # the same tree read from HBM instead of LDS, and walked in time slices (what scenes too
             # large for LDS and trees deeper than 16 levels get): the same frame, the same ray count
             # (and with two entries of each lane's stack in LDS, the rest in device memory)
-            for flags, slice_steps, entries in ((api.RT_FLAG_NO_LDS_SCENE, 0, 0), (0, 3, 0), (api.RT_FLAG_NO_LDS_SCENE, 5, 0),
-                                                 (api.RT_FLAG_NO_LDS_SCENE | api.RT_FLAG_FLOAT_NODES, 0, 0), (api.RT_FLAG_NO_LDS_SCENE, 7, 2)):
-                other = ctx.render_host(api.Context.params(W, H, spp, 50, 77 + seed, flags=flags, traversal_slice=slice_steps, stack_lds_entries=entries))
-                assert np.array_equal(other, img), (accel, flags, slice_steps, entries)
+            # (the last number: the share of unfinished lanes at which a wave leaves a time-sliced walk, in 128ths; -1 = never for that)
+            for flags, slice_steps, entries, share in ((api.RT_FLAG_NO_LDS_SCENE, 0, 0, 0), (0, 3, 0, -1), (api.RT_FLAG_NO_LDS_SCENE, 5, 0, -1),
+                                                        (api.RT_FLAG_NO_LDS_SCENE | api.RT_FLAG_FLOAT_NODES, 0, 0, 0), (api.RT_FLAG_NO_LDS_SCENE, 7, 2, 0),
+                                                        (0, 40, 0, 96), (api.RT_FLAG_NO_LDS_SCENE, 200, 0, 32)):
+                other = ctx.render_host(api.Context.params(W, H, spp, 50, 77 + seed, flags=flags, traversal_slice=slice_steps, stack_lds_entries=entries,
+                                                           traversal_exit_share=share))
+                assert np.array_equal(other, img), (accel, flags, slice_steps, entries, share)
                 assert ctx.stats()["rays"] == st["rays"]
         if accel == api.RT_ACCEL_BVH:
             # three interleaved shards of 4-row tiles, another tile shape: the same bits
@@ -232,6 +235,9 @@ def test_random_sphere_field(seed, oracle):
             # time-sliced, with three entries of each lane's stack in LDS and the rest in device memory
             assert np.array_equal(ctx.render_host(api.Context.params(W, H, spp, depth, 9 + seed, flags=api.RT_FLAG_NO_LDS_SCENE, traversal_slice=24,
                                                                       stack_lds_entries=3)), img)
+            assert np.array_equal(ctx.render_host(api.Context.params(W, H, spp, depth, 9 + seed, flags=api.RT_FLAG_NO_LDS_SCENE, traversal_slice=24,
+                                                                      traversal_exit_share=-1)), img)
+            assert np.array_equal(ctx.render_host(api.Context.params(W, H, spp, depth, 9 + seed, traversal_slice=500, traversal_exit_share=112)), img)
         ctx.close()
         if first is None:
             first = img

@@ -73,7 +73,8 @@ def test_rejected_calls_leave_the_context_usable(api, rtiow_flat):
     bad.prim_mat[3] = 10 ** 6                               # refers outside the material array
     with pytest.raises(api.RtError):
         c.upload_scene(bad)
-    for kw in (dict(lanes_per_pixel=5), dict(tiles=(0, 3, 2)), dict(flags=api.RT_FLAG_FIXED_SUMS | api.RT_FLAG_MEAN)):
+    for kw in (dict(lanes_per_pixel=5), dict(tiles=(0, 3, 2)), dict(flags=api.RT_FLAG_FIXED_SUMS | api.RT_FLAG_MEAN),
+               dict(traversal_exit_share=129), dict(traversal_exit_share=-2), dict(stack_lds_entries=49)):
         with pytest.raises(api.RtError):
             c.render_host(api.Context.params(80, 60, 3, 50, 11, **kw))
     c.upload_scene(rtiow_flat)

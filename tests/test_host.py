@@ -26,6 +26,7 @@ def test_struct_sizes_match_header_layout():
     assert C.sizeof(api.Hit) == 44 and api.HIT_DTYPE.itemsize == 44
     # (the 56-byte layout without the tuning fields and the 64-byte one without stack_lds_entries are accepted too)
     assert C.sizeof(api.RenderParams) == 72 and api.RenderParams.traversal_slice.offset == 56 and api.RenderParams.stack_lds_entries.offset == 64
+    assert api.RenderParams.traversal_exit_share.offset == 68          # (in what was padding behind stack_lds_entries)
     assert C.sizeof(api.CameraDesc) == 13 * 8
 
 
