@@ -144,11 +144,13 @@ typedef struct rt_render_params {
                                     deeper tree's walk keeps the rest in device memory the context allocates.  0 = default
                                     (24: what leaves six workgroups per CU), else 2 .. 48.  A struct whose struct_size ends
                                     before this field leaves it at the default. */
-    int32_t traversal_exit_share; /* time-sliced walk: the wavefront also leaves the walk as soon as the lanes whose walk is
-                                    unfinished are no more than this many 128ths of the lanes that came in with one
-                                    (finished lanes then shade and start new rays while most of them are free): 0 = default
-                                    (64: half), -1 = off, else 1 .. 128.  Read with stack_lds_entries (it fills what was
-                                    padding behind it: zero the struct). */
+    int32_t traversal_exit_share; /* the wavefront also leaves a walk as soon as the lanes whose walk is unfinished are no
+                                    more than this many 128ths of the lanes that came in with one (finished lanes then
+                                    shade and start new rays while most of them are free; the others resume): in a
+                                    time-sliced walk after any step, in the plain walk of a shallower tree between two
+                                    rounds of leaves (scenes of spheres only, traversal_slice 0).  0 = default (64 and 32),
+                                    -1 = off, else 1 .. 128.  Read with stack_lds_entries (it fills what was padding
+                                    behind it: zero the struct). */
 } rt_render_params;
 
 /* one closest-hit answer (hit_record of sceneobject.h:9-14 plus the object's list position) */

@@ -217,7 +217,7 @@ int validate_render(rt_context* ctx, const rt_render_params* p, rt::DRender* rp)
     const int share = has_stack ? p->traversal_exit_share : 0;
     if (share < -1 || share > 128) return fail(ctx, RT_ERR_INVALID, "traversal_exit_share must be -1, 0 or in [1, 128]");
     // device side: steps in the low 16 bits (0xffff = chosen at launch from the tree depth, 0 = unsliced), exit share above them
-    rp->slice = (slice == 0 ? 0xffff : (slice < 0 ? 0 : (slice > 65534 ? 65534 : slice))) | ((share == 0 ? rt::kExitShare : (share < 0 ? 0 : share)) << 16);
+    rp->slice = (slice == 0 ? 0xffff : (slice < 0 ? 0 : (slice > 65534 ? 65534 : slice))) | ((share == 0 ? 255 : (share < 0 ? 0 : share)) << 16);
     rp->leaf_quorum = quorum == 0 ? -1 : (quorum < 0 ? 0 : quorum);     // device side: -1 = default ratio, 0 = wait for all
     const int lds_entries = has_stack ? p->stack_lds_entries : 0;
     if (lds_entries != 0 && (lds_entries < 2 || lds_entries > rt::kMaxStack))

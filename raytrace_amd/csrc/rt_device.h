@@ -111,7 +111,7 @@ struct DRender {
     int lanes_per_pixel;                    // K: power of two, 1..64; a wave's tile holds 64/K pixels
     float inv_wm1, inv_hm1;                 // 1/(W-1), 1/(H-1)  (main.cc:117-118)
     int stack_depth;                        // size of the LDS traversal stack in units of kBlock ints (tree depth + 2 entries per lane; 16-bit entries with the tree in LDS)
-    int slice;                              // low 16 bits: node steps a wave spends on traversal per trip (0 = no limit, 0xffff = choose at launch); above them: exit share in 128ths (0 = none)
+    int slice;                              // low 16 bits: node steps a wave spends on traversal per trip (0 = no limit, 0xffff = choose at launch); above them: exit share in 128ths (0 = none, 255 = the default of the walk that is launched)
     int leaf_quorum;                        // time-sliced walk: leaves are tested once (lanes waiting at a leaf) x this >= lanes still walking (0 = wait for all, -1 = default)
     int stack_cap;                          // most entries the LDS stack of a walk out of HBM may hold before it spills (kLdsStackCap, or the caller's)
     int stack_entries;                      // entries per lane the LDS stack holds (the walk spills beyond them where the kernel is built for it)
@@ -126,6 +126,7 @@ constexpr int kNoBvh = 0x7fffffff;
 constexpr int kLdsStackCap = 24;            // LDS stack entries of a walk out of HBM that still leave six workgroups per CU (24 KB + 2 KB of accumulators each)
 constexpr int kSpillLanes = 256 * 6 * 256;  // lanes of the largest grid such a kernel is launched with (256 CUs x 6 workgroups x 256 threads)
 constexpr int kExitShare = 64;             // a time-sliced walk is also left once no more than this many 128ths of the lanes that came in are unfinished
+constexpr int kRoundShare = 32;            // the same for a plain walk that is left between rounds of leaves
 constexpr int kMaxStack = 48;               // deepest BVH the traversal stack holds
 
 struct Hit {              // rt_hit of include/rt.h, device side (same layout)

@@ -557,7 +557,7 @@ __device__ __forceinline__ int pop_ref(unsigned top) {
     if constexpr (SHORT) return (int)*(lds_short*)(size_t)top; else return *(lds_int*)(size_t)top;
 }
 
-template <bool COUNT, bool SLICED, class G>
+template <bool COUNT, int SL, class G>     // SL: 0 a walk ends in the call; 1 time slices; 2 left between rounds only
 __device__ __forceinline__ void hit_bvh(const G& geo, V3 o, const RayN& rn, Origin from, int* stack, int lds_entries, int budget, int quorum,
                                         int& cur, int& sp, Cand& best, Counters& cn) {
     const V3 dh = rn.dh;
@@ -605,9 +605,10 @@ __device__ __forceinline__ void hit_bvh(const G& geo, V3 o, const RayN& rn, Orig
     bool stop = false;
     // (SLICED) budget = steps | share << 16: the wave also leaves the walk as soon as the lanes whose walk
     // is unfinished are no more than share / 128 of the lanes that came in
-    const int exit_ratio = SLICED ? budget >> 16 : 0;
-    if constexpr (SLICED) budget &= 0xffff;
-    const int entered = SLICED ? __popcll(__ballot(true)) : 0;
+    constexpr bool SLICED = SL == 1, RESUMED = SL != 0;
+    const int exit_ratio = RESUMED ? budget >> 16 : 0;
+    if constexpr (RESUMED) budget &= 0xffff;
+    const int entered = RESUMED ? __popcll(__ballot(true)) : 0;
     while (cur != kDone && !stop) {
         // Deep trees: a lane meets a leaf every seven or eight node steps, and waiting until all 64
         // lanes stand on one leaves most of them idle for most of the walk.  The wave therefore
@@ -691,9 +692,12 @@ __device__ __forceinline__ void hit_bvh(const G& geo, V3 o, const RayN& rn, Orig
             if constexpr (G::kDeep) cur = top >= limit ? geo.spill[(top - limit) / kStackStride] : pop_ref<false>(top);
             else cur = pop_ref<G::kPlaneAddressed>(top);
         }
+        // (SL == 2) the plain walk, left after a round of leaves once the lanes with an unfinished walk
+        // are no more than share / 128 of those that came in: one ballot a round, none per step
+        if constexpr (SL == 2) stop = __popcll(__ballot(cur != kDone)) * 128 <= entered * exit_ratio;
     }
     // (a finished walk leaves top one entry below the bottom: its sp is not used again)
-    if constexpr (SLICED) sp = (int)(top - bottom) / (int)kStackStride;
+    if constexpr (RESUMED) sp = (int)(top - bottom) / (int)kStackStride;
 }
 
 // ---- hit record ------------------------------------------------------------------------------
@@ -1120,13 +1124,13 @@ __device__ __forceinline__ float from_fixed(unsigned long long q) { return (floa
 // one ray on all 64 lanes until the tile runs out of samples, whatever the path lengths were.
 // Dynamic LDS: [traversal stack: stack_depth x kBlock ints, a lane's column starting with the entry that ends a walk][accumulators and pixel tables: 4 waves x (8P + 1) u64]
 // then, for the LDS-resident variant, [nodes][spheres][list positions].
-// MODE: 0 linear scan, 1 BVH, 2 BVH walked in time slices.  Each combination is a kernel of its
+// MODE: 0 linear scan, 1 BVH, 2 BVH walked in time slices, 3 BVH walk that may be left between rounds of leaves.  Each combination is a kernel of its
 // own: code that a scene never runs (rects, the scan, the tree walk) still costs the code that
 // does run registers and scheduling freedom when it shares a kernel with it.
 template <bool COUNT, bool LDS, bool PROF, int MODE, bool RECTS, int QUANT>
 __global__ __launch_bounds__(kBlock, MODE == 0 ? RT_WG_PER_CU_SCAN : (LDS ? RT_WG_PER_CU : RT_WG_PER_CU_HBM)) void render_kernel(DScene sc, DCamera cam, DRender rp, float4* __restrict__ out,
                                                         unsigned long long* __restrict__ counters) {
-    constexpr bool SLICED = MODE == 2, BVH = MODE != 0;
+    constexpr bool SLICED = MODE >= 2, BVH = MODE != 0;
     extern __shared__ __align__(16) int s_dyn[];
     // (16-bit entries with the tree in LDS: see hit_bvh)
     int* stack = (LDS && MODE != 0) ? reinterpret_cast<int*>(reinterpret_cast<short*>(s_dyn) + threadIdx.x) : s_dyn + threadIdx.x;
@@ -1307,7 +1311,7 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? RT_WG_PER_CU_SCAN : (LDS ? RT_W
             }
             if (PROF) { unsigned long long t = clk(); ph[1] += t - tq; tq = t; }
             if constexpr (BVH)
-                if (curq != kDone) hit_bvh<COUNT, SLICED>(geo, o, rn, from, stack, rp.stack_entries, rp.slice, rp.leaf_quorum, curq, spq, cq, cn);
+                if (curq != kDone) hit_bvh<COUNT, MODE == 2 ? 1 : (MODE == 3 ? 2 : 0)>(geo, o, rn, from, stack, rp.stack_entries, rp.slice, rp.leaf_quorum, curq, spq, cq, cn);
             if (PROF) { unsigned long long t = clk(); ph[2] += t - tq; tq = t; }
             if (curq == kDone) {                       // query finished (else: resumed next trip)
                 if (shade<COUNT, RECTS>(sc, geo, rp, cq, key, depth, refine, rn, o, d, T, L, from, cn)) {
@@ -1352,7 +1356,7 @@ __device__ __forceinline__ Cand closest_hit(const DScene& sc, V3 o, V3 d, float 
     if (!sc.use_bvh) hit_list<COUNT, false>(sc, nullptr, o, rn, no_origin(), best, cn);
     else if (sc.root != kNoBvh) {
         int cur = sc.root, sp = 0;
-        hit_bvh<COUNT, false>(geo, o, rn, no_origin(), stack, kMaxStack, 0, 0, cur, sp, best, cn);
+        hit_bvh<COUNT, 0>(geo, o, rn, no_origin(), stack, kMaxStack, 0, 0, cur, sp, best, cn);
     }
     return best;
 }
@@ -1462,16 +1466,28 @@ hipError_t launch_render(const DScene& sc, const DCamera& cam, const DRender& rp
     // Up to 16 levels the plain walk is as fast or faster (2 x 10^4 spheres, 15 levels: 9.8 ms
     // against 10.9; 3.5 x 10^4, 16 levels: 13.7 against 14.0; 5 x 10^4, 16 levels: 16.7 against
     // 16.4; 7 x 10^4, 18 levels: 22.1 against 19.3).  The image does not depend on it.
+    // A tree of at most 16 levels under nothing but spheres is walked plainly, and the walk is left
+    // between two rounds of leaves once a quarter of the lanes that came in, or fewer, are unfinished
+    // (one ballot a round; those lanes resume next trip, like a time slice's): the default scene
+    // 18.4 -> 17.5 ms, 5 x 10^4 spheres 16.9 -> 16.2, 2 x 10^4 spheres and the default scene's
+    // tree read from HBM unchanged.  With rects or textures in the scene it loses (a world of image
+    // textures and boxes 14.2 -> 15.3 ms: the lanes that resume a walk sit out the always-tested
+    // primitives of the lanes that start a ray), so there the walk stays whole.
+    bool rounds = false;
     {
-        int steps = r.slice & 0xffff;
-        if (steps == 0xffff) steps = sc.bvh_depth > 16 ? 64 : 0;
-        r.slice = steps > 0 ? (steps | (r.slice & ~0xffff)) : 0;
+        int steps = r.slice & 0xffff, share = (r.slice >> 16) & 0xff;
+        const bool chosen = steps == 0xffff;
+        if (chosen) steps = sc.bvh_depth > 16 ? 64 : 0;
+        rounds = chosen && steps == 0 && share > 0 && sc.use_bvh && sc.n_rects == 0 && !sc.has_textures &&
+                 (in_lds || (sc.qnodes != nullptr && (rp.flags & 128u) == 0u));
+        if (share == 255) share = steps > 0 ? kExitShare : kRoundShare;
+        r.slice = (steps > 0 || rounds) ? (steps | (share << 16)) : 0;
     }
     // (with six waves per SIMD on a tree in HBM the walkers may be a little fewer before the wave
     // turns to its leaves: 10^6 spheres -2.5 % against a ratio of 2)
     if (r.leaf_quorum < 0) r.leaf_quorum = in_lds ? 2 : 4;
 
-    const bool sliced = sc.use_bvh && r.slice > 0;
+    const bool sliced = sc.use_bvh && (r.slice & 0xffff) > 0;
     // A tree in HBM deeper than kLdsStackCap - 2 levels: the LDS stack stops at kLdsStackCap entries (more
     // would cost a workgroup per CU, the sixth wave per SIMD that hides the fetches) and the rest of a
     // lane's stack lives in the scene's spill array (only the quantised walk is built that way)
@@ -1498,8 +1514,8 @@ hipError_t launch_render(const DScene& sc, const DCamera& cam, const DRender& rp
 #define RT_LAUNCH_R(C, L, P, M) do { if (sc.n_rects > 0 || sc.has_textures) RT_LAUNCH_Q(C, L, P, M, true); else RT_LAUNCH_Q(C, L, P, M, false); } while (0)
 #define RT_LAUNCH_M(C, P) do { \
         if (!sc.use_bvh) { if (in_lds) RT_LAUNCH_R(C, true, P, 0); else RT_LAUNCH_R(C, false, P, 0); } \
-        else if (in_lds) { if (sliced) RT_LAUNCH_R(C, true, P, 2); else RT_LAUNCH_R(C, true, P, 1); } \
-        else { if (sliced) RT_LAUNCH_R(C, false, P, 2); else RT_LAUNCH_R(C, false, P, 1); } \
+        else if (in_lds) { if (sliced) RT_LAUNCH_R(C, true, P, 2); else if (rounds) RT_LAUNCH(C, true, P, 3, false, 0); else RT_LAUNCH_R(C, true, P, 1); } \
+        else { if (sliced) RT_LAUNCH_R(C, false, P, 2); else if (rounds) RT_LAUNCH(C, false, P, 3, false, 1); else RT_LAUNCH_R(C, false, P, 1); } \
     } while (0)
     if (prof) RT_LAUNCH_M(false, true);
     else if (count) RT_LAUNCH_M(true, false);

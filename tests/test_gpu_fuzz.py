@@ -132,7 +132,9 @@ def test_random_scene(seed, oracle):
             # (the last number: the share of unfinished lanes at which a wave leaves a time-sliced walk, in 128ths; -1 = never for that)
             for flags, slice_steps, entries, share in ((api.RT_FLAG_NO_LDS_SCENE, 0, 0, 0), (0, 3, 0, -1), (api.RT_FLAG_NO_LDS_SCENE, 5, 0, -1),
                                                         (api.RT_FLAG_NO_LDS_SCENE | api.RT_FLAG_FLOAT_NODES, 0, 0, 0), (api.RT_FLAG_NO_LDS_SCENE, 7, 2, 0),
-                                                        (0, 40, 0, 96), (api.RT_FLAG_NO_LDS_SCENE, 200, 0, 32)):
+                                                        (0, 40, 0, 96), (api.RT_FLAG_NO_LDS_SCENE, 200, 0, 32),
+                                                        # (whole walks; scenes of spheres only: walks left between rounds of leaves)
+                                                        (0, -1, 0, 0), (0, 0, 0, 128), (api.RT_FLAG_NO_LDS_SCENE, 0, 0, 100)):
                 other = ctx.render_host(api.Context.params(W, H, spp, 50, 77 + seed, flags=flags, traversal_slice=slice_steps, stack_lds_entries=entries,
                                                            traversal_exit_share=share))
                 assert np.array_equal(other, img), (accel, flags, slice_steps, entries, share)
@@ -238,6 +240,10 @@ def test_random_sphere_field(seed, oracle):
             assert np.array_equal(ctx.render_host(api.Context.params(W, H, spp, depth, 9 + seed, flags=api.RT_FLAG_NO_LDS_SCENE, traversal_slice=24,
                                                                       traversal_exit_share=-1)), img)
             assert np.array_equal(ctx.render_host(api.Context.params(W, H, spp, depth, 9 + seed, traversal_slice=500, traversal_exit_share=112)), img)
+            # the walk that is never left early, and the one left between rounds of leaves at two other shares
+            for flags, sl, share in ((0, -1, 0), (api.RT_FLAG_NO_LDS_SCENE, -1, 0), (0, 0, 128), (api.RT_FLAG_NO_LDS_SCENE, 0, 8), (0, 0, -1)):
+                assert np.array_equal(ctx.render_host(api.Context.params(W, H, spp, depth, 9 + seed, flags=flags, traversal_slice=sl,
+                                                                          traversal_exit_share=share)), img), (flags, sl, share)
         ctx.close()
         if first is None:
             first = img

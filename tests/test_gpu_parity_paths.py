@@ -496,3 +496,26 @@ def test_a_stack_that_spills_out_of_lds_loses_no_node(api, S):
         with pytest.raises(api.RtError):
             ctx.render_host(P(W, H, 2, 1, 5, stack_lds_entries=1))
         ctx.close()
+
+
+def test_a_walk_left_between_rounds_of_leaves_is_the_same_walk(api, S):
+    """A scene of spheres only under a tree of at most 16 levels: by default a wave leaves the walk
+    between two rounds of leaves once a quarter of the lanes that came in are unfinished, and those
+    lanes resume on the next trip.  The frame and its ray count are those of the walk that is never
+    left (traversal_slice -1), at any share (128: left after every round), with the tree in LDS or
+    read from HBM, at full depth and with the depth limit at 1."""
+    flat = S.flatten(S.rtiow_scene())
+    ctx = api.Context(0)
+    ctx.upload_scene(flat, accel=api.RT_ACCEL_BVH)
+    ctx.set_camera(**S.rtiow_camera(1.5).desc())
+    W, H = 240, 160
+    P = api.Context.params
+    for lds in (0, api.RT_FLAG_NO_LDS_SCENE):
+        for depth, spp in ((50, 8), (1, 3)):
+            whole = ctx.render_host(P(W, H, spp, depth, 3, flags=lds, traversal_slice=-1))
+            rays = ctx.stats()["rays"]
+            for share in (0, 1, 16, 127, 128, -1):
+                got = ctx.render_host(P(W, H, spp, depth, 3, flags=lds, traversal_exit_share=share))
+                assert np.array_equal(got, whole), (lds, depth, share)
+                assert ctx.stats()["rays"] == rays
+    ctx.close()
