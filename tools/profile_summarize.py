@@ -38,7 +38,7 @@ for name, ctrs in per_kernel.items():
 
 # the timed kernel: the plain build (first template argument false) with the most launches
 # (c2 also launches the linear scan, whose fourth template argument, the closest-hit mode, is 0)
-plain = [n for n in out if "render_kernel<false" in n and (cfg != "c2" or "false, 1, " in n)]
+plain = [n for n in out if "render_kernel<false" in n and (cfg != "c2" or "false, 0, " not in n)]
 main = max(plain, key=lambda n: out[n]["launches_per_pass"]) if plain else None
 if main:
     c = out[main]
