@@ -21,6 +21,9 @@
 #ifndef RT_WG_PER_CU
 #define RT_WG_PER_CU 5                 // workgroups of 256 threads per CU = waves per SIMD the tree-walking kernels are compiled for
 #endif
+#ifndef RT_WG_PER_CU_ROUNDS
+#define RT_WG_PER_CU_ROUNDS 5          // the same for walks in LDS that may be left between rounds of leaves (16 registers spill; at 4, without spills: 17.5 -> 19.3 ms)
+#endif
 #ifndef RT_WG_PER_CU_HBM
 #define RT_WG_PER_CU_HBM 6             // the same for walks of a tree in HBM: more waves to wait on memory with
 #endif
@@ -1128,7 +1131,7 @@ __device__ __forceinline__ float from_fixed(unsigned long long q) { return (floa
 // own: code that a scene never runs (rects, the scan, the tree walk) still costs the code that
 // does run registers and scheduling freedom when it shares a kernel with it.
 template <bool COUNT, bool LDS, bool PROF, int MODE, bool RECTS, int QUANT>
-__global__ __launch_bounds__(kBlock, MODE == 0 ? RT_WG_PER_CU_SCAN : (LDS ? RT_WG_PER_CU : RT_WG_PER_CU_HBM)) void render_kernel(DScene sc, DCamera cam, DRender rp, float4* __restrict__ out,
+__global__ __launch_bounds__(kBlock, MODE == 0 ? RT_WG_PER_CU_SCAN : (LDS ? (MODE == 3 ? RT_WG_PER_CU_ROUNDS : RT_WG_PER_CU) : RT_WG_PER_CU_HBM)) void render_kernel(DScene sc, DCamera cam, DRender rp, float4* __restrict__ out,
                                                         unsigned long long* __restrict__ counters) {
     constexpr bool SLICED = MODE >= 2, BVH = MODE != 0;
     extern __shared__ __align__(16) int s_dyn[];
@@ -1501,7 +1504,7 @@ hipError_t launch_render(const DScene& sc, const DCamera& cam, const DRender& rp
     // persistent waves: enough workgroups to fill 256 CUs at the kernel's occupancy, never more
     // than there are tiles
     static_assert(kSpillLanes == 256 * RT_WG_PER_CU_HBM * kBlock, "one spill strip per lane of the largest grid");
-    const int wg_per_cu = sc.use_bvh ? (in_lds ? RT_WG_PER_CU : RT_WG_PER_CU_HBM) : RT_WG_PER_CU_SCAN;
+    const int wg_per_cu = sc.use_bvh ? (in_lds ? (rounds ? RT_WG_PER_CU_ROUNDS : RT_WG_PER_CU) : RT_WG_PER_CU_HBM) : RT_WG_PER_CU_SCAN;
     if (blocks > 256 * wg_per_cu) blocks = 256 * wg_per_cu;
     const bool count = (rp.flags & 4u) != 0u;
     const bool prof = (rp.flags & 8u) != 0u;
