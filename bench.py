@@ -53,18 +53,90 @@ def executed_flops(st):
             misses * F_MISS + st["samples"] * F_CAMERA)
 
 
-def measured_traffic(config):
-    """HBM bytes per render launch from the committed PMC passes (FETCH_SIZE / WRITE_SIZE are
-    collected with rocprofv3 in runs of their own, so they cannot be read inside this process)."""
+NODE_BYTES = 32                   # one node visit of a walk out of HBM reads a 32-byte quantised node (two box tests)
+PEAK_HBM_GBS = 8000.0             # MI355X HBM3E
+
+
+def _traffic_file(config):
     import glob
     name = "hbm_traffic.json" if config == "c2" else f"{config}_hbm_traffic.json"
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", name)))
     if not files:
         return None
     try:
-        return json.load(open(files[-1]))["hbm_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
+        return json.load(open(files[-1]))
+    except (OSError, ValueError):
         return None
+
+
+def measured_traffic(config):
+    """HBM bytes per render launch from the committed PMC passes (FETCH_SIZE / WRITE_SIZE are
+    collected with rocprofv3 in runs of their own, so they cannot be read inside this process)."""
+    d = _traffic_file(config)
+    return d.get("hbm_bytes_per_launch") if d else None
+
+
+def memory_side(config, cst, kernel_ms, width, height):
+    """The bandwidth side of the roofline, for a reader to check `bound` against: the bytes the
+    algorithm asks the memory system for per launch (framebuffer + one 32-byte node per node
+    visit when the tree is walked out of HBM; counting launch of the same kernel), what of that
+    missed L2 (committed PMC passes of the same command), and both over the launch's duration."""
+    fb = width * height * 16
+    walked_from_hbm = config == "c4"
+    nodes = (cst["box_tests"] // 2) * NODE_BYTES if walked_from_hbm else 0
+    d = _traffic_file(config) or {}
+    miss = d.get("hbm_bytes_per_launch")
+    wr = d.get("WRITE_SIZE_KB_per_launch")
+    out = {"framebuffer_bytes": fb, "node_bytes_requested": nodes, "algorithmic_bytes_per_launch": fb + nodes,
+           "requested_GBs": (fb + nodes) / (kernel_ms * 1e-3) / 1e9,
+           "l2_miss_bytes": miss, "l2_miss_GBs": miss / (kernel_ms * 1e-3) / 1e9 if miss else None,
+           "l2_miss_frac_of_hbm_peak": miss / (kernel_ms * 1e-3) / 1e9 / PEAK_HBM_GBS if miss else None,
+           "write_bytes": wr * 1024 if wr else None, "peak_hbm_GBs": PEAK_HBM_GBS,
+           "note": "node_bytes_requested = 32 B x node visits, served by L1 / L2 / Infinity Cache (the scene stays resident); "
+                   "l2_miss_bytes = FETCH_SIZE x2 + WRITE_SIZE of the committed PMC passes (upper bound)"}
+    return out
+
+
+def lone_frames(name, device, stream_ptr, frames=3):
+    """One more configuration under this run's clock: `frames` launches of its frame, one at a time
+    (HIP events around each, on the stream it runs on), then the counting launch of the same kernel
+    for the executed work.  The frame is the configuration's own size and sample count."""
+    import torch
+    from raytrace_amd import api
+    wl = Workload(name)
+    ctx = api.Context(device)
+    ctx.set_stream(stream_ptr)
+    t0 = time.perf_counter()
+    ctx.upload_scene(wl.flat, accel=wl.accel)
+    upload_s = time.perf_counter() - t0
+    cam, seed = wl.camera_of_step(1 if wl.path else 0)
+    ctx.set_camera(**cam)
+    buf = torch.zeros((wl.H, wl.W, 4), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    ms, st = [], None
+    t0 = time.perf_counter()
+    for _ in range(frames):
+        ctx.render(api.Context.params(wl.W, wl.H, wl.spp, wl.depth, seed), buf.data_ptr())
+        st = ctx.stats()                                     # waits for the launch
+        ms.append(st["kernel_ms"])
+    wall_ms = (time.perf_counter() - t0) / frames * 1e3
+    ctx.render(api.Context.params(wl.W, wl.H, wl.spp, wl.depth, seed, flags=api.RT_FLAG_COUNTERS), buf.data_ptr())
+    cst = ctx.stats()
+    ctx.close()
+    del buf
+    kernel_ms = sum(ms) / len(ms)
+    flops = executed_flops(cst)
+    out = {"workload": wl.label, "width": wl.W, "height": wl.H, "spp": wl.spp, "frames": frames,
+           "kernel_ms": kernel_ms, "kernel_ms_each": ms, "wall_ms_per_frame": wall_ms,
+           "rays_per_frame": st["rays"], "mrays_s": st["rays"] / kernel_ms / 1e3,
+           "frac": flops / (kernel_ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS, "achieved_tflops": flops / (kernel_ms * 1e-3) / 1e12,
+           "flops_per_ray": flops / max(cst["rays"], 1),
+           "tests_per_ray": {k: cst[k] / max(cst["rays"], 1) for k in ("box_tests", "sphere_tests", "sphere_hits", "rect_tests", "wide_tests")},
+           "traversal_lane_utilisation": cst["phase_clocks"][0] / (64.0 * cst["phase_clocks"][1]) if cst["phase_clocks"][1] else None,
+           "lanes_per_pixel": st["lanes_per_pixel"], "bvh_depth": st["bvh_depth"], "upload_s": upload_s}
+    if name == "c4":
+        out["memory_side"] = memory_side(name, cst, kernel_ms, wl.W, wl.H)
+    return out
 
 
 class Workload:
@@ -195,6 +267,8 @@ def main():
                     help="how N > 1 ranks share the work (default: tiles; c5: frames+samples)")
     ap.add_argument("--spp", type=int, default=None, help="override the config's samples per pixel (rehearsals)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="c2 on one GPU: do not render the lone frames of c3, c4 and c5 after the timed region")
     ap.add_argument("--accel", choices=["bvh", "list"], default="bvh")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo: rehearse the N-rank path on fewer GPUs (ranks share devices, shards exchanged via host)")
@@ -499,6 +573,18 @@ def main():
             allh = [held]
         frame_ok = all(int(h[1]) == 1 for h in allh) and sum(int(h[0]) for h in allh) == args.steps
 
+    # the other configurations under the same run's clock (after the timed region, one launch at a
+    # time): three frames each of c3 and c4 and one of the camera path, at their own sizes and
+    # sample counts
+    other = None
+    if world == 1 and not dist_on and args.config == "c2" and args.accel == "bvh" and not args.no_other_configs and not args.spp:
+        for c in ctxs:
+            c.close()
+        del fbufs
+        torch.cuda.empty_cache()
+        sp = torch.cuda.current_stream().cuda_stream
+        other = {"c3": lone_frames("c3", device, sp, 3), "c4": lone_frames("c4", device, sp, 3), "c5": lone_frames("c5", device, sp, 1)}
+
     if rank == 0:
         if not dist_on:
             how = "single GPU"
@@ -540,6 +626,9 @@ def main():
                                  "of the one before it, so ms_per_step is shorter than kernel_ms; the conservative "
                                  "one-launch-at-a-time rate is one_launch_at_a_time_mrays_s"},
         }
+        out["roofline"]["memory_side"] = memory_side(args.config, cst, kernel_ms, W, H) if world == 1 else None
+        if other is not None:
+            out["other_configs"] = other
         if frame_ok is not None:
             out["frame_matches_single_gpu"] = frame_ok
         if world == 1 and not args.no_cpu_baseline:

@@ -87,6 +87,7 @@ int main(int argc, char** argv) {
     auto finish = [&](int frame, int s) -> int {
         HIP_OK(hipStreamSynchronize(stream[s]));
         rt_stats st{};
+        st.struct_size = sizeof(st);
         RT_CHECK(ctx[s], rt_get_stats(ctx[s], &st));
         rays += st.rays; kernel_ms += st.kernel_ms;
         const std::string path = out_dir + "/ppm_images/image_" + std::to_string(frame) + "_low.ppm";

@@ -111,6 +111,9 @@ enum {
     RT_FLAG_NO_LDS_SCENE = 1u << 5, /* read BVH and spheres from HBM even when they would fit in LDS */
     RT_FLAG_FLOAT_NODES = 1u << 7, /* a tree read from HBM is walked through its 64-byte single-precision nodes
                                      instead of the 32-byte quantised ones (same image; for comparison) */
+    RT_FLAG_ALL_FEATURES = 1u << 8, /* render with the kernel that carries the code of every scene feature (rects, textures,
+                                     instance transforms) instead of the one built for what this scene holds (same image;
+                                     for comparison) */
     RT_FLAG_FIXED_SUMS = 1u << 6  /* the image is written as the kernel accumulates it: per pixel four uint64_t
                                      (r, g, b sums of sample radiance in unsigned 32.32 fixed point, sample
                                      count), 32 bytes.  Integer sums of sample windows (sample_begin) add up
@@ -118,6 +121,14 @@ enum {
                                      the frame one call renders with all the samples.  Excludes RT_FLAG_MEAN. */
 };
 
+/* Range of a pixel: the kernels keep a pixel's sum of sample radiance per channel in unsigned 32.32 fixed
+ * point (what makes an image independent of the order samples are added in, on one GPU or many), so the
+ * sum must stay below 2^32, where main.cc:121 sums in double.  A sample is at most the scene's brightest
+ * emitter or background colour (albedos are at most 1), so rt_render and rt_render_host return
+ * RT_ERR_UNSUPPORTED when (sample_begin + spp) x that brightness reaches 2^32 -- an emitter of 10^7 takes at
+ * most 429 samples -- instead of wrapping; split such a frame into calls of fewer samples and combine their
+ * means in floating point.  (Integer sums of sample windows added by the caller, RT_FLAG_FIXED_SUMS, are the
+ * caller's to keep below 2^32 per channel in the same way; an albedo above 1 is not accounted for.) */
 typedef struct rt_render_params {
     uint32_t struct_size;        /* sizeof(rt_render_params) */
     int32_t width, height;       /* full image, also when only some row tiles are rendered */
@@ -136,10 +147,11 @@ typedef struct rt_render_params {
      * traversal_slice leaves all of it at the defaults. */
     int32_t traversal_slice;     /* BVH node steps a wavefront spends per trip of its path loop before lanes whose
                                     rays are finished shade and start new rays: 0 = chosen from the tree depth,
-                                    -1 = never leave a walk early, n > 0 = n steps (at most 65534) */
+                                    -1 = never leave a walk early, n > 0 = n steps (at most 65534; more is
+                                    RT_ERR_INVALID) */
     int32_t leaf_quorum;         /* time-sliced walk: leaves are tested once (lanes waiting at a leaf) x this
                                     >= lanes still walking; 0 = default (2 with the tree in LDS, 4 with it in
-                                    device memory), -1 = wait for every lane */
+                                    device memory), -1 = wait for every lane, at most 64 (a wavefront's lanes) */
     int32_t stack_lds_entries;   /* time-sliced walk of a tree in HBM: entries of a lane's traversal stack kept in LDS; a
                                     deeper tree's walk keeps the rest in device memory the context allocates.  0 = default
                                     (24: what leaves six workgroups per CU), else 2 .. 48.  A struct whose struct_size ends
@@ -164,6 +176,10 @@ typedef struct rt_hit {
 } rt_hit;
 
 typedef struct rt_stats {
+    uint32_t struct_size;        /* IN: sizeof(rt_stats) as the caller was compiled; rt_get_stats writes that many bytes
+                                    at most, so the struct can grow at its end without writing past an older caller's
+                                    object (since version 0.3: the layout before it had no such field) */
+    uint32_t reserved;
     uint64_t rays;               /* closest-hit queries (one per world.hit call, main.cc:18) */
     uint64_t samples;            /* camera samples */
     uint64_t box_tests, sphere_tests, sphere_hits, rect_tests, wide_tests, shades; /* RT_FLAG_COUNTERS */
@@ -211,8 +227,9 @@ int rt_trace_primary(rt_context* ctx, const float* rays_host, int32_t n, float t
  * library's code object (RT_TRACE_NOALLOC_MAX_RAYS rays: 1.5 MB of rays + 3 MB of hits per GPU, held until
  * the process ends), so the call makes no hipMalloc / hipFree and never grows anything.  n above the
  * maximum is RT_ERR_UNSUPPORTED (split the batch).  Every call on one GPU, from any context, uses that
- * GPU's one array: calls that overlap in time on one GPU race (give them to one thread, or one after the
- * other); calls on different GPUs are independent.  The host arrays are copied with hipMemcpyAsync:
+ * GPU's one array: calls of one process on one GPU take turns (a lock per GPU inside the library, held
+ * until the call's answers are on the host), so contexts driven by different threads may call it freely;
+ * calls on different GPUs are independent.  The host arrays are copied with hipMemcpyAsync:
  * pass pinned memory where the runtime's own staging of pageable memory is not acceptable either. */
 #define RT_TRACE_NOALLOC_MAX_RAYS 65536
 int rt_trace_primary_noalloc(rt_context* ctx, const float* rays_host, int32_t n, float t_min, rt_hit* hits_host);
@@ -226,7 +243,9 @@ int rt_quantize(rt_context* ctx, const float* rgba_device, int64_t n_pixels, int
  * sums.  Asynchronous on the context's stream. */
 int rt_resolve_sums(rt_context* ctx, const uint64_t* sums_device, int64_t n_pixels, int32_t mean, float* rgba_device);
 
-/* Waits for the context's stream, then reports the last render. */
+/* Waits for the context's stream, then reports the last render.  out->struct_size must be set by the caller
+ * to sizeof(rt_stats) of the header it was compiled against; a size smaller than the struct of version 0.3
+ * (which ends with bvh_coarse_nodes) is RT_ERR_INVALID. */
 int rt_get_stats(rt_context* ctx, rt_stats* out);
 
 const char* rt_last_error(rt_context* ctx);

@@ -352,7 +352,7 @@ public:
         check(rt_render_host(ctx_, &p, out.data()), "rt_render_host");
         return out;
     }
-    rt_stats stats() { rt_stats s{}; check(rt_get_stats(ctx_, &s), "rt_get_stats"); return s; }
+    rt_stats stats() { rt_stats s{}; s.struct_size = sizeof(s); check(rt_get_stats(ctx_, &s), "rt_get_stats"); return s; }
     rt_context* context() { return ctx_; }
 
 private:

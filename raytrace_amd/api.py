@@ -16,6 +16,7 @@ RT_ERR_INVALID, RT_ERR_NO_DEVICE, RT_ERR_HIP, RT_ERR_NO_SCENE, RT_ERR_NO_CAMERA,
 RT_ACCEL_AUTO, RT_ACCEL_LIST, RT_ACCEL_BVH, RT_ACCEL_BVH_DEVICE = 0, 1, 2, 3
 TRACE_NOALLOC_MAX_RAYS = 65536           # RT_TRACE_NOALLOC_MAX_RAYS
 RT_FLAG_MEAN, RT_FLAG_NO_REFINE, RT_FLAG_COUNTERS, RT_FLAG_PHASE_CLOCKS, RT_FLAG_NO_LDS_SCENE, RT_FLAG_FIXED_SUMS, RT_FLAG_FLOAT_NODES = 1, 2, 4, 8, 32, 64, 128
+RT_FLAG_ALL_FEATURES = 256
 
 EXPORTS = ["rt_create", "rt_destroy", "rt_set_stream", "rt_upload_scene", "rt_set_camera",
            "rt_shard_rows", "rt_render", "rt_render_host", "rt_trace_primary", "rt_trace_primary_noalloc", "rt_quantize",
@@ -67,7 +68,8 @@ HIT_DTYPE = np.dtype([("id", "<i4"), ("t", "<f4"), ("p", "<f4", 3), ("n", "<f4",
 
 
 class Stats(C.Structure):
-    _fields_ = [("rays", C.c_uint64), ("samples", C.c_uint64), ("box_tests", C.c_uint64),
+    _fields_ = [("struct_size", C.c_uint32), ("reserved", C.c_uint32),
+                ("rays", C.c_uint64), ("samples", C.c_uint64), ("box_tests", C.c_uint64),
                 ("sphere_tests", C.c_uint64), ("sphere_hits", C.c_uint64), ("rect_tests", C.c_uint64),
                 ("wide_tests", C.c_uint64), ("shades", C.c_uint64), ("phase_clocks", C.c_uint64 * 5),
                 ("kernel_ms", C.c_float),
@@ -288,5 +290,6 @@ class Context:
 
     def stats(self):
         s = Stats()
+        s.struct_size = C.sizeof(Stats)
         self._check(lib().rt_get_stats(self._h, C.byref(s)))
         return s.as_dict()

@@ -31,6 +31,7 @@ struct rt_context {
     int accel_used = RT_ACCEL_LIST;
     int bvh_nodes = 0, bvh_depth = 0;
     float build_ms = 0.0f;
+    double max_radiance = 1.0;     // brightest thing a sample can see: emitters and the background (see validate_render)
     int coarse_nodes = 0;          // nodes the 16-bit grid is too coarse for (any: the tree is walked in its float form)
     int* stack_spill = nullptr;    // deep trees walked out of HBM: a strip per lane for the stack entries beyond the LDS stack
     int stack_spill_entries = 0;   // entries per strip
@@ -61,8 +62,9 @@ static __device__ __align__(256) unsigned char scratch[kNoAllocRayBytes + kNoAll
 static_assert(kNoAllocRayBytes % 256 == 0, "the hits start on a 256-byte boundary");
 
 constexpr int kMaxDevices = 64;
-std::mutex g_scratch_mutex;
+std::mutex g_scratch_mutex;                       // guards g_scratch_ptr
 unsigned char* g_scratch_ptr[kMaxDevices] = {};
+std::mutex g_scratch_in_use[kMaxDevices];         // one call at a time per GPU stages through that GPU's array
 
 // Device address of `scratch` on `device`, which must be the current device.
 hipError_t resolve_scratch(int device, unsigned char** out) {
@@ -191,6 +193,12 @@ int validate_render(rt_context* ctx, const rt_render_params* p, rt::DRender* rp)
         return fail(ctx, RT_ERR_INVALID, "spp >= 1, sample_begin >= 0, max_depth >= 0 required");
     if ((long long)p->sample_begin + p->spp > 0x7fffffffLL)
         return fail(ctx, RT_ERR_INVALID, "sample range overflows");
+    // a pixel's sum of sample radiance must stay below 2^32 (32.32 fixed point): the samples up to the end
+    // of this call's window, each at most the scene's brightest emitter
+    if (((double)p->sample_begin + (double)p->spp) * ctx->max_radiance >= 4294967296.0)
+        return fail(ctx, RT_ERR_UNSUPPORTED, "a pixel's radiance sum could reach 2^32: " + std::to_string((long long)p->sample_begin + p->spp) +
+                                             " samples of an emitter (or background) of " + std::to_string(ctx->max_radiance) +
+                                             "; render fewer samples per call and combine the means in floating point");
     bool whole = p->tile_rows == 0 && p->tile_first == 0 && p->tile_step == 0;
     if (!whole && (p->tile_rows < 1 || p->tile_step < 1 || p->tile_first < 0 || p->tile_first >= p->tile_step))
         return fail(ctx, RT_ERR_INVALID, "tiles: tile_rows >= 1, 0 <= tile_first < tile_step required");
@@ -213,11 +221,13 @@ int validate_render(rt_context* ctx, const rt_render_params* p, rt::DRender* rp)
     rp->inv_wm1 = (float)(1.0 / (double)(p->width - 1));
     rp->inv_hm1 = (float)(1.0 / (double)(p->height - 1));
     const int slice = has_tuning ? p->traversal_slice : 0, quorum = has_tuning ? p->leaf_quorum : 0;
-    if (slice < -1 || quorum < -1) return fail(ctx, RT_ERR_INVALID, "traversal_slice and leaf_quorum must be >= -1");
+    // (the kernel multiplies the quorum by a lane count: 64 lanes make anything above 64 mean the same)
+    if (slice < -1 || slice > 65534 || quorum < -1 || quorum > 64)
+        return fail(ctx, RT_ERR_INVALID, "traversal_slice must be in [-1, 65534] and leaf_quorum in [-1, 64]");
     const int share = has_stack ? p->traversal_exit_share : 0;
     if (share < -1 || share > 128) return fail(ctx, RT_ERR_INVALID, "traversal_exit_share must be -1, 0 or in [1, 128]");
     // device side: steps in the low 16 bits (0xffff = chosen at launch from the tree depth, 0 = unsliced), exit share above them
-    rp->slice = (slice == 0 ? 0xffff : (slice < 0 ? 0 : (slice > 65534 ? 65534 : slice))) | ((share == 0 ? 255 : (share < 0 ? 0 : share)) << 16);
+    rp->slice = (slice == 0 ? 0xffff : (slice < 0 ? 0 : slice)) | ((share == 0 ? 255 : (share < 0 ? 0 : share)) << 16);
     rp->leaf_quorum = quorum == 0 ? -1 : (quorum < 0 ? 0 : quorum);     // device side: -1 = default ratio, 0 = wait for all
     const int lds_entries = has_stack ? p->stack_lds_entries : 0;
     if (lds_entries != 0 && (lds_entries < 2 || lds_entries > rt::kMaxStack))
@@ -253,7 +263,7 @@ int do_render(rt_context* ctx, const rt::DRender& rp, float4* out_dev) {   // wi
 
 extern "C" {
 
-const char* rt_version(void) { return "raytrace_amd 0.1 (gfx950)"; }
+const char* rt_version(void) { return "raytrace_amd 0.3 (gfx950)"; }
 
 int rt_create(int device, rt_context** out) {
     if (!out) return RT_ERR_INVALID;
@@ -389,6 +399,24 @@ int rt_upload_scene(rt_context* ctx, const rt_scene_desc* d) {
             const float r0_front = (1.0f - inv_ir) / (1.0f + inv_ir), r0_back = (1.0f - m.ir) / (1.0f + m.ir);
             m.r = inv_ir; m.g = r0_front * r0_front; m.b = r0_back * r0_back;
         }
+    }
+
+    // The brightest radiance a sample can return: a path's throughput is a product of albedos (at most 1
+    // for any physical material), so a sample is at most the brightest emitter or the background.  A
+    // pixel's sum is kept in unsigned 32.32 fixed point: rt_render refuses a sample count that could
+    // carry it past 2^32 instead of letting it wrap (main.cc:121 sums in double, which does not).
+    double max_radiance = d->background == RT_BG_SKY ? 1.0 : std::fmax(d->bg_color[0], std::fmax(d->bg_color[1], d->bg_color[2]));
+    {
+        std::vector<double> tex_max((size_t)d->n_tex, 1.0);       // image textures: bytes / 255
+        for (int pass = 0; pass < 9; pass++)                      // checkers nest at most 8 deep (checked above)
+            for (int i = 0; i < d->n_tex; i++) {
+                if (texs[i].type == RT_TEX_SOLID) tex_max[i] = std::fmax(texs[i].r, std::fmax(texs[i].g, texs[i].bl));
+                else if (texs[i].type == RT_TEX_CHECKER) tex_max[i] = std::fmax(tex_max[texs[i].a], tex_max[texs[i].b]);
+            }
+        for (const rt::DMaterial& m : mats)
+            if (m.type == RT_DIFFUSE_LIGHT || m.type == RT_LAMBERTIAN_BG)
+                max_radiance = std::fmax(max_radiance, m.tex >= 0 ? tex_max[m.tex] : std::fmax(m.r, std::fmax(m.g, m.b)));
+        if (!(max_radiance >= 0.0)) max_radiance = 0.0;           // (NaN colours render as 0)
     }
 
     // instance transforms: sine and cosine in double (cuda/sceneobject.h:50-52 takes them in float)
@@ -585,6 +613,15 @@ int rt_upload_scene(rt_context* ctx, const rt_scene_desc* d) {
     s.ids_fit_16 = (d->n_prims < 65536 && d->n_mats < 65536) ? 1 : 0;
     s.has_textures = 0;
     for (const rt::DMaterial& m : mats) if (m.tex >= 0) s.has_textures = 1;
+    // instance transforms the kernels have to look at: a rect's, and a sphere's where its material may
+    // read a texture (a turned sphere is the sphere about the moved centre; only its texture turns)
+    bool instances = false;
+    for (const rt::DRect& r : rects) if (r.axes >> 8) instances = true;
+    if (s.has_textures) {
+        if (any_sphere_xf) instances = true;
+        for (const rt::DWide& w : wide) if (w.xform) instances = true;
+    }
+    if (instances) s.has_textures |= 2;
     s.n_wide = (int)wide.size();
     s.n_rects = (int)rects.size();
     s.background = d->background;
@@ -593,6 +630,7 @@ int rt_upload_scene(rt_context* ctx, const rt_scene_desc* d) {
     ctx->accel_used = use_bvh ? RT_ACCEL_BVH : RT_ACCEL_LIST;
     ctx->bvh_nodes = n_nodes;
     ctx->bvh_depth = depth;
+    ctx->max_radiance = max_radiance;
     ctx->has_scene = true;
     return RT_OK;
 }
@@ -699,6 +737,9 @@ int rt_trace_primary_noalloc(rt_context* ctx, const float* rays_host, int32_t n,
     if (n == 0) return RT_OK;
     if (!ctx->noalloc) return fail(ctx, RT_ERR_HIP, "rt_trace_primary_noalloc: the staging array has no device address");
     DeviceGuard g(ctx->device);
+    // every context and thread of this process shares the GPU's one array: calls on one GPU take turns
+    // (the call waits for its stream anyway, so the lock costs nothing a lone caller could notice)
+    std::lock_guard<std::mutex> turn(g_scratch_in_use[ctx->device]);
     // rays in the first part of the array, hits behind them.  Nothing has to start at zero: the
     // copy writes rays [0, n), the kernel writes every hit of [0, n) and only those are read back,
     // so what an earlier (longer) call left behind n is never looked at.
@@ -743,22 +784,31 @@ int rt_resolve_sums(rt_context* ctx, const uint64_t* sums_device, int64_t n_pixe
 
 int rt_get_stats(rt_context* ctx, rt_stats* out) {
     if (!ctx || !out) return RT_ERR_INVALID;
+    // the caller says how large its rt_stats is; fields added after its header was written are not
+    // written into it
+    constexpr size_t kFirstSized = offsetof(rt_stats, bvh_coarse_nodes) + sizeof(int32_t);
+    const size_t caller = out->struct_size;
+    if (caller < kFirstSized) return fail(ctx, RT_ERR_INVALID, "rt_stats: set struct_size to sizeof(rt_stats) before the call");
     DeviceGuard g(ctx->device);
-    std::memset(out, 0, sizeof(*out));
+    rt_stats st;
+    std::memset(&st, 0, sizeof(st));
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     unsigned long long c[rt::kNumCounters + rt::kNumPhaseClocks];
     RT_HIP(ctx, hipMemcpy(c, ctx->counters, sizeof(c), hipMemcpyDeviceToHost));
-    out->rays = c[0]; out->samples = c[1];
-    out->box_tests = c[2]; out->sphere_tests = c[3]; out->sphere_hits = c[4];
-    out->rect_tests = c[5]; out->wide_tests = c[6]; out->shades = c[7];
-    for (int q = 0; q < rt::kNumPhaseClocks; q++) out->phase_clocks[q] = c[rt::kNumCounters + q];
-    if (ctx->timed) RT_HIP(ctx, hipEventElapsedTime(&out->kernel_ms, ctx->ev_start, ctx->ev_stop));
-    out->lanes_per_pixel = ctx->last_k;
-    out->accel = ctx->accel_used;
-    out->bvh_nodes = ctx->bvh_nodes;
-    out->bvh_depth = ctx->bvh_depth;
-    out->build_ms = ctx->build_ms;
-    out->bvh_coarse_nodes = ctx->coarse_nodes;
+    st.rays = c[0]; st.samples = c[1];
+    st.box_tests = c[2]; st.sphere_tests = c[3]; st.sphere_hits = c[4];
+    st.rect_tests = c[5]; st.wide_tests = c[6]; st.shades = c[7];
+    for (int q = 0; q < rt::kNumPhaseClocks; q++) st.phase_clocks[q] = c[rt::kNumCounters + q];
+    if (ctx->timed) RT_HIP(ctx, hipEventElapsedTime(&st.kernel_ms, ctx->ev_start, ctx->ev_stop));
+    st.lanes_per_pixel = ctx->last_k;
+    st.accel = ctx->accel_used;
+    st.bvh_nodes = ctx->bvh_nodes;
+    st.bvh_depth = ctx->bvh_depth;
+    st.build_ms = ctx->build_ms;
+    st.bvh_coarse_nodes = ctx->coarse_nodes;
+    const size_t n = caller < sizeof(rt_stats) ? caller : sizeof(rt_stats);
+    st.struct_size = (uint32_t)n;
+    std::memcpy(out, &st, n);
     return RT_OK;
 }
 

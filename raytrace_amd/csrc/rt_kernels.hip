@@ -327,7 +327,13 @@ using GeoGlobalQ = GeoGlobalQT<false>;
 // all twelve and selecting; the selects were a fifth of the node step's VALU time and LDS has
 // bandwidth to spare.  Inner-node references are the nodes' LDS byte addresses in units of 16
 // bytes ((node_base + index * 80) / 16), leaves keep their negative codes.
-constexpr int kLdsNodeBytes = 80;
+#ifndef RT_LDS_NODE_WORDS
+#define RT_LDS_NODE_WORDS 20
+#endif
+constexpr int kLdsNodeBytes = 4 * RT_LDS_NODE_WORDS;
+// inner-node references in LDS: the node's byte address >> kLdsRefShift (16-byte units for the
+// 80-byte node; an 84-byte node, whose bases spread over all 32 banks, is addressed in dwords)
+constexpr int kLdsRefShift = (RT_LDS_NODE_WORDS % 4 == 0) ? 4 : 2;
 typedef const float __attribute__((address_space(3))) lds_cfloat;
 typedef const int __attribute__((address_space(3))) lds_cint;
 typedef int __attribute__((address_space(3))) lds_int;
@@ -340,7 +346,7 @@ struct GeoLds {
     unsigned node_base;                                          // LDS byte address of node 0
     const float4* sph; const int* objs;                          // both point into LDS
     V3 reach;
-    __device__ __forceinline__ int root_ref(int root) const { return root >= 0 ? (int)((node_base + (unsigned)root * kLdsNodeBytes) >> 4) : root; }   // a tiny scene's root is a leaf
+    __device__ __forceinline__ int root_ref(int root) const { return root >= 0 ? (int)((node_base + (unsigned)root * kLdsNodeBytes) >> kLdsRefShift) : root; }   // a tiny scene's root is a leaf
     __device__ __forceinline__ float4 sphere(int i) const { return sph[i]; }
     // list position and material share a word (both below 65536 in a scene that fits in LDS)
     __device__ __forceinline__ int obj(int i) const { return objs[i] & 0xffff; }
@@ -411,9 +417,16 @@ __device__ __forceinline__ RayN normalise(V3 d, float t_min) {
 
 // Always-tested primitives: wide spheres (double) and rects.  They run first and tighten the
 // distance bound the BVH traversal prunes with.
-// RECTS = false compiles the rect and the texture code out (kernels for scenes of plainly coloured
-// spheres: that code is never run there, but its registers and size slowed the sphere path by 3 %).
-template <bool COUNT, bool RECTS>
+// FEAT: what the scene holds besides plainly coloured spheres (kFeat* bits).  Each kernel carries the
+// code of its scene's features only: code a scene never runs still costs the code that does run
+// registers and scheduling freedom when both share a kernel (the rect code: 3 % of a frame of
+// spheres; the texture code in the room of rects and the rect and instance code in the field of
+// textured spheres: the registers those kernels spilled).
+//   kFeatRects      rects (cuda/rect.h:29-52)
+//   kFeatTextures   some material reads a texture (cuda/texture.h:17-78): surface coordinates, texture_value
+//   kFeatInstances  some primitive stands under rotate_y / translate (cuda/sceneobject.h:31-109)
+constexpr int kFeatRects = 1, kFeatTextures = 2, kFeatInstances = 4, kFeatAll = 7;
+template <bool COUNT, int FEAT>
 __device__ __forceinline__ void hit_always(const DScene& sc, V3 o, V3 d, const RayN& rn, float t_min, Origin from,
                                            Cand& best, Counters& cn) {
     const int from_wide = from.wide(), from_rect = from.rect();
@@ -426,6 +439,7 @@ __device__ __forceinline__ void hit_always(const DScene& sc, V3 o, V3 d, const R
             best.tn = tn; best.kind = 1; best.idx = i; best.obj = w.obj;
         }
     }
+    constexpr bool RECTS = (FEAT & kFeatRects) != 0, INST = (FEAT & kFeatInstances) != 0;
     V3 inv_d = mk(0.0f, 0.0f, 0.0f);
     if constexpr (RECTS)
         if (sc.n_rects > 0) inv_d = mk(polished_rcp(d.x), polished_rcp(d.y), polished_rcp(d.z));
@@ -440,7 +454,7 @@ __device__ __forceinline__ void hit_always(const DScene& sc, V3 o, V3 d, const R
         // per plane axis, each on the ray's components themselves
         bool hit;
         const int ka = __builtin_amdgcn_readfirstlane(r.axes & 3);
-        if (r.axes >> 8) {                   // instance: a rotation keeps |d|, so t means the same
+        if (INST && (r.axes >> 8)) {         // instance: a rotation keeps |d|, so t means the same
             const ObjRay q = to_object(sc.xforms[(r.axes >> 8) - 1], o, d, ka, sc.rect_k[i]);
             if (ka == 0) hit = rect_test<0>(r, q.num, polished_rcp(q.d.x), q.o, q.d, t_min, kInf, t);
             else if (ka == 1) hit = rect_test<1>(r, q.num, polished_rcp(q.d.y), q.o, q.d, t_min, kInf, t);
@@ -630,10 +644,10 @@ __device__ __forceinline__ void hit_bvh(const G& geo, V3 o, const RayN& rn, Orig
             if constexpr (G::kPlaneAddressed) {
                 // per axis: words 0 and 3 from the ray's address are the planes it enters the left and
                 // the right child through, words 1 and 4 the ones it leaves through
-                lds_cfloat* px = (lds_cfloat*)(size_t)(((unsigned)cur << 4) + enter_x);
-                lds_cfloat* py = (lds_cfloat*)(size_t)(((unsigned)cur << 4) + enter_y);
-                lds_cfloat* pz = (lds_cfloat*)(size_t)(((unsigned)cur << 4) + enter_z);
-                lds_cint* refs = (lds_cint*)(size_t)(((unsigned)cur << 4) + 72u);
+                lds_cfloat* px = (lds_cfloat*)(size_t)(((unsigned)cur << kLdsRefShift) + enter_x);
+                lds_cfloat* py = (lds_cfloat*)(size_t)(((unsigned)cur << kLdsRefShift) + enter_y);
+                lds_cfloat* pz = (lds_cfloat*)(size_t)(((unsigned)cur << kLdsRefShift) + enter_z);
+                lds_cint* refs = (lds_cint*)(size_t)(((unsigned)cur << kLdsRefShift) + 72u);
                 left = refs[0]; right = refs[1];
                 float l_ex = px[0], r_ex = px[3], l_lx = px[1], r_lx = px[4];
                 float l_ey = py[0], r_ey = py[3], l_ly = py[1], r_ly = py[4];
@@ -739,9 +753,11 @@ __device__ __forceinline__ void face(Rec& r, V3 d, V3 outward) {
 // f(t) = a t^2 + 2 hb t + c in double from the single-precision root (the correction itself is
 // a float division), then p and the normal from the polished t.
 // `s64` is the winning ordinary sphere in double and `mat` its material, both loaded by the caller.
-template <bool RECTS>
+template <int FEAT>
 __device__ __forceinline__ Rec make_record(const DScene& sc, const Cand& c, V3 o, V3 d, float inv_len, bool refine, bool want_uv,
                                            double4 s64, int mat) {
+    constexpr bool RECTS = (FEAT & kFeatRects) != 0, TEX = (FEAT & kFeatTextures) != 0, INST = (FEAT & kFeatInstances) != 0;
+    if constexpr (!TEX) want_uv = false;
     Rec r;
     r.obj = c.obj;
     r.u = 0.0f; r.v = 0.0f;
@@ -757,7 +773,7 @@ __device__ __forceinline__ Rec make_record(const DScene& sc, const Cand& c, V3 o
         // the hit lies in the rect's plane: that coordinate of the point is k itself (as the
         // reference's o + t d is to 1e-12), not a single-precision o + t d, which strays by an ulp
         // of the scene's coordinates and lets a solid texture flip where it changes across the plane
-        if (q.axes >> 8) {
+        if (INST && (q.axes >> 8)) {
             // the instance's own hit record, then point and normal back in the world.  The side
             // of the surface is the one the instance saw (cuda/sceneobject.h:105 asks again with
             // the object-space ray against the world-space normal, which mixes the two frames).
@@ -787,9 +803,10 @@ __device__ __forceinline__ Rec make_record(const DScene& sc, const Cand& c, V3 o
         const DWide w = sc.wide[c.idx];
         cx = w.cx; cy = w.cy; cz = w.cz; rad = w.r;
         r.mat = w.mat;
-        xform = w.xform;
+        if constexpr (INST) xform = w.xform;
     } else {
-        if (want_uv && sc.sph_xform) xform = sc.sph_xform[c.idx];
+        if constexpr (INST)
+            if (want_uv && sc.sph_xform) xform = sc.sph_xform[c.idx];
         r.mat = mat;
         cx = s64.x; cy = s64.y; cz = s64.z; rad = s64.w;
     }
@@ -1027,25 +1044,26 @@ __device__ __forceinline__ unsigned long long clk() { return __builtin_amdgcn_s_
 
 // Shade one finished closest-hit query: returns true when the path ended (sample complete).
 // L collects the path's radiance: emitted light along the way and the background at the end.
-template <bool COUNT, bool RECTS, class G>
+template <bool COUNT, int FEAT, class G>
 __device__ __forceinline__ bool shade(const DScene& sc, const G& geo, const DRender& rp, const Cand& c, const Key& key, int depth,
                                       bool refine, const RayN& rn, V3& o, V3& d, V3& T, V3& L, Origin& from, Counters& cn) {
     if (c.kind < 0) {
         L = L + T * background(sc, rn.dh);
         return true;
     }
+    constexpr bool RECTS = (FEAT & kFeatRects) != 0, TEX = (FEAT & kFeatTextures) != 0;
     // the loads the record and the material need go out first; the Philox block below is pure
     // arithmetic and runs while they are in flight
     const int mat = c.kind == 0 ? geo.mat(c.idx) : ((!RECTS || c.kind == 1) ? sc.wide[c.idx].mat : sc.rects[c.idx].mat);
     const double4 s64 = c.kind == 0 ? sc.sph64[c.idx] : make_double4(0.0, 0.0, 0.0, 1.0);
     DMaterial m = sc.mats[mat];
-    if (!RECTS) m.tex = -1;        // a kernel without the rect code serves scenes without textures too: none of that code is kept
+    if (!TEX) m.tex = -1;          // a kernel for scenes without textures keeps none of that code
     // one Philox block per scatter segment, shared by whichever material consumes it
     // (the fused exclusive-or wherever the geometry is in LDS or the kernel carries no rect and texture
     // code: the walk out of HBM with that code is the one kernel it costs registers it does not have;
     // the kernels that read their geometry from HBM want their loads kept behind the block: rt_philox.h)
-    const uint4 w = philox4x32_10<!RECTS || G::kPlaneAddressed, !G::kPlaneAddressed>(key.pixel, key.sample, (uint32_t)depth, 0u, key.seed_lo, key.seed_hi);
-    Rec r = make_record<RECTS>(sc, c, o, d, rn.inv_len, refine, m.tex >= 0, s64, mat);
+    const uint4 w = philox4x32_10<FEAT == 0 || G::kPlaneAddressed, !G::kPlaneAddressed>(key.pixel, key.sample, (uint32_t)depth, 0u, key.seed_lo, key.seed_hi);
+    Rec r = make_record<FEAT>(sc, c, o, d, rn.inv_len, refine, m.tex >= 0, s64, mat);
     V3 att, sd, em;
     if (COUNT) cn.shade++;
     V3 rs = mk(0.0f, 0.0f, 0.0f);
@@ -1088,8 +1106,8 @@ __device__ __forceinline__ typename GeoOf<LDS, QUANT>::type stage_geometry(const
             n[0] = q0.x; n[1] = q0.w; n[2] = q0.x; n[3] = q1.z; n[4] = q2.y; n[5] = q1.z;
             n[6] = q0.y; n[7] = q1.x; n[8] = q0.y; n[9] = q1.w; n[10] = q2.z; n[11] = q1.w;
             n[12] = q0.z; n[13] = q1.y; n[14] = q0.z; n[15] = q2.x; n[16] = q2.w; n[17] = q2.x;
-            n[18] = __int_as_float(l >= 0 ? (int)((base + (unsigned)l * kLdsNodeBytes) >> 4) : l);
-            n[19] = __int_as_float(r >= 0 ? (int)((base + (unsigned)r * kLdsNodeBytes) >> 4) : r);
+            n[18] = __int_as_float(l >= 0 ? (int)((base + (unsigned)l * kLdsNodeBytes) >> kLdsRefShift) : l);
+            n[19] = __int_as_float(r >= 0 ? (int)((base + (unsigned)r * kLdsNodeBytes) >> kLdsRefShift) : r);
         }
         for (int i = threadIdx.x; i < sc.n_sph; i += kBlock) { sph[i] = sc.sph[i]; int2 f = sc.sph_info[i]; objs[i] = f.x | (f.y << 16); }
         for (int i = sc.n_sph + threadIdx.x; i < sc.n_sph_padded; i += kBlock) { sph[i] = sc.sph[i]; objs[i] = 0; }   // the scan's padding
@@ -1130,7 +1148,7 @@ __device__ __forceinline__ float from_fixed(unsigned long long q) { return (floa
 // MODE: 0 linear scan, 1 BVH, 2 BVH walked in time slices, 3 BVH walk that may be left between rounds of leaves.  Each combination is a kernel of its
 // own: code that a scene never runs (rects, the scan, the tree walk) still costs the code that
 // does run registers and scheduling freedom when it shares a kernel with it.
-template <bool COUNT, bool LDS, bool PROF, int MODE, bool RECTS, int QUANT>
+template <bool COUNT, bool LDS, bool PROF, int MODE, int FEAT, int QUANT>
 __global__ __launch_bounds__(kBlock, MODE == 0 ? RT_WG_PER_CU_SCAN : (LDS ? (MODE == 3 ? RT_WG_PER_CU_ROUNDS : RT_WG_PER_CU) : RT_WG_PER_CU_HBM)) void render_kernel(DScene sc, DCamera cam, DRender rp, float4* __restrict__ out,
                                                         unsigned long long* __restrict__ counters) {
     constexpr bool SLICED = MODE >= 2, BVH = MODE != 0;
@@ -1278,7 +1296,7 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? RT_WG_PER_CU_SCAN : (LDS ? (MOD
                 if (x >= 0) {
                     key.pixel = (uint32_t)(j * rp.width + x);
                     key.sample = (uint32_t)rp.sample_begin + (uint32_t)(u >> logP);
-                    camera_ray<!RECTS || LDS, !LDS>(s_cam, rp, key, x, j, o, d);
+                    camera_ray<FEAT == 0 || LDS, !LDS>(s_cam, rp, key, x, j, o, d);
                     T = mk(1.0f, 1.0f, 1.0f);
                     L = mk(0.0f, 0.0f, 0.0f);
                     depth = 0;
@@ -1306,7 +1324,7 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? RT_WG_PER_CU_SCAN : (LDS ? (MOD
             int& spq = *(SLICED ? &sp : &sp_trip);
             if (curq == kDone) {                       // a new ray: always-tested primitives first
                 cq = no_hit();
-                hit_always<COUNT, RECTS>(sc, o, d, rn, rp.t_min, from, cq, cn);
+                hit_always<COUNT, FEAT>(sc, o, d, rn, rp.t_min, from, cq, cn);
                 nrays++;
                 depth++;
                 if constexpr (!BVH) hit_list<COUNT, LDS>(sc, staged_list, o, rn, from, cq, cn);
@@ -1317,7 +1335,7 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? RT_WG_PER_CU_SCAN : (LDS ? (MOD
                 if (curq != kDone) hit_bvh<COUNT, MODE == 2 ? 1 : (MODE == 3 ? 2 : 0)>(geo, o, rn, from, stack, rp.stack_entries, rp.slice, rp.leaf_quorum, curq, spq, cq, cn);
             if (PROF) { unsigned long long t = clk(); ph[2] += t - tq; tq = t; }
             if (curq == kDone) {                       // query finished (else: resumed next trip)
-                if (shade<COUNT, RECTS>(sc, geo, rp, cq, key, depth, refine, rn, o, d, T, L, from, cn)) {
+                if (shade<COUNT, FEAT>(sc, geo, rp, cq, key, depth, refine, rn, o, d, T, L, from, cn)) {
                     atomicAdd(&accum[q * 3 + 0], to_fixed(L.x));
                     atomicAdd(&accum[q * 3 + 1], to_fixed(L.y));
                     atomicAdd(&accum[q * 3 + 2], to_fixed(L.z));
@@ -1354,7 +1372,7 @@ template <bool COUNT, int QUANT>
 __device__ __forceinline__ Cand closest_hit(const DScene& sc, V3 o, V3 d, float t_min, int* stack, Counters& cn) {
     Cand best = no_hit();
     RayN rn = normalise(d, t_min);
-    hit_always<COUNT, true>(sc, o, d, rn, t_min, no_origin(), best, cn);
+    hit_always<COUNT, kFeatAll>(sc, o, d, rn, t_min, no_origin(), best, cn);
     const auto geo = stage_geometry<false, QUANT>(sc, nullptr);
     if (!sc.use_bvh) hit_list<COUNT, false>(sc, nullptr, o, rn, no_origin(), best, cn);
     else if (sc.root != kNoBvh) {
@@ -1383,7 +1401,7 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(DScene sc, const float* _
         for (int a = 0; a < 3; a++) { h.p[a] = 0.0f; h.n[a] = 0.0f; }
     } else {
         const double4 s64 = c.kind == 0 ? sc.sph64[c.idx] : make_double4(0.0, 0.0, 0.0, 1.0);
-        Rec r = make_record<true>(sc, c, o, d, normalise(d, t_min).inv_len, (flags & 2u) == 0u, true, s64, c.kind == 0 ? sc.sph_info[c.idx].y : 0);
+        Rec r = make_record<kFeatAll>(sc, c, o, d, normalise(d, t_min).inv_len, (flags & 2u) == 0u, true, s64, c.kind == 0 ? sc.sph_info[c.idx].y : 0);
         h.id = r.obj; h.t = r.t; h.front = r.front; h.u = r.u; h.v = r.v;
         h.p[0] = r.p.x; h.p[1] = r.p.y; h.p[2] = r.p.z;
         h.n[0] = r.n.x; h.n[1] = r.n.y; h.n[2] = r.n.z;
@@ -1481,7 +1499,7 @@ hipError_t launch_render(const DScene& sc, const DCamera& cam, const DRender& rp
         int steps = r.slice & 0xffff, share = (r.slice >> 16) & 0xff;
         const bool chosen = steps == 0xffff;
         if (chosen) steps = sc.bvh_depth > 16 ? 64 : 0;
-        rounds = chosen && steps == 0 && share > 0 && sc.use_bvh && sc.n_rects == 0 && !sc.has_textures &&
+        rounds = chosen && steps == 0 && share > 0 && sc.use_bvh && sc.n_rects == 0 && !sc.has_textures && (rp.flags & 256u) == 0u &&
                  (in_lds || (sc.qnodes != nullptr && (rp.flags & 128u) == 0u));
         if (share == 255) share = steps > 0 ? kExitShare : kRoundShare;
         r.slice = (steps > 0 || rounds) ? (steps | (share << 16)) : 0;
@@ -1512,19 +1530,27 @@ hipError_t launch_render(const DScene& sc, const DCamera& cam, const DRender& rp
 #define RT_LAUNCH(...) hipLaunchKernelGGL((render_kernel<__VA_ARGS__>), grid, block, lds, stream, sc, cam, r, out, counters)
     // a tree read from HBM is walked through its 32-byte quantised nodes
     const bool quant = sc.use_bvh && !in_lds && sc.qnodes != nullptr && (rp.flags & 128u) == 0u;
-#define RT_LAUNCH_Q(C, L, P, M, R) do { if (!L && M == 2 && quant && deep) RT_LAUNCH(C, L, P, M, R, ((!L && M == 2) ? 2 : 0)); \
-        else if (!L && M != 0 && quant) RT_LAUNCH(C, L, P, M, R, ((!L && M != 0) ? 1 : 0)); else RT_LAUNCH(C, L, P, M, R, 0); } while (0)
-#define RT_LAUNCH_R(C, L, P, M) do { if (sc.n_rects > 0 || sc.has_textures) RT_LAUNCH_Q(C, L, P, M, true); else RT_LAUNCH_Q(C, L, P, M, false); } while (0)
+    // what the scene holds besides plainly coloured spheres picks the kernel (see hit_always).  Instances
+    // come with everything else (scenes of turned boxes are rooms with textures more often than not); the
+    // counting and the phase-clock builds (diagnostics: their counts do not depend on it) exist without
+    // any of it and with all of it
+    int feat = (sc.n_rects > 0 ? kFeatRects : 0) | ((sc.has_textures & 1) ? kFeatTextures : 0) | ((sc.has_textures & 2) ? kFeatInstances : 0);
+    if ((feat & kFeatInstances) || ((count || prof) && feat != 0) || (rp.flags & 256u) != 0u) feat = kFeatAll;
+#define RT_LAUNCH_Q(C, L, P, M, F) do { if (!L && M == 2 && quant && deep) RT_LAUNCH(C, L, P, M, F, ((!L && M == 2) ? 2 : 0)); \
+        else if (!L && M != 0 && quant) RT_LAUNCH(C, L, P, M, F, ((!L && M != 0) ? 1 : 0)); else RT_LAUNCH(C, L, P, M, F, 0); } while (0)
+#define RT_LAUNCH_F(C, L, P, M) do { if (feat == 0) RT_LAUNCH_Q(C, L, P, M, 0); else if (feat == kFeatAll) RT_LAUNCH_Q(C, L, P, M, kFeatAll); \
+        else if constexpr (!C && !P) { if (feat == kFeatRects) RT_LAUNCH_Q(C, L, P, M, kFeatRects); else if (feat == kFeatTextures) RT_LAUNCH_Q(C, L, P, M, kFeatTextures); \
+                                       else RT_LAUNCH_Q(C, L, P, M, (kFeatRects | kFeatTextures)); } } while (0)
 #define RT_LAUNCH_M(C, P) do { \
-        if (!sc.use_bvh) { if (in_lds) RT_LAUNCH_R(C, true, P, 0); else RT_LAUNCH_R(C, false, P, 0); } \
-        else if (in_lds) { if (sliced) RT_LAUNCH_R(C, true, P, 2); else if (rounds) RT_LAUNCH(C, true, P, 3, false, 0); else RT_LAUNCH_R(C, true, P, 1); } \
-        else { if (sliced) RT_LAUNCH_R(C, false, P, 2); else if (rounds) RT_LAUNCH(C, false, P, 3, false, 1); else RT_LAUNCH_R(C, false, P, 1); } \
+        if (!sc.use_bvh) { if (in_lds) RT_LAUNCH_F(C, true, P, 0); else RT_LAUNCH_F(C, false, P, 0); } \
+        else if (in_lds) { if (sliced) RT_LAUNCH_F(C, true, P, 2); else if (rounds) RT_LAUNCH(C, true, P, 3, 0, 0); else RT_LAUNCH_F(C, true, P, 1); } \
+        else { if (sliced) RT_LAUNCH_F(C, false, P, 2); else if (rounds) RT_LAUNCH(C, false, P, 3, 0, 1); else RT_LAUNCH_F(C, false, P, 1); } \
     } while (0)
     if (prof) RT_LAUNCH_M(false, true);
     else if (count) RT_LAUNCH_M(true, false);
     else RT_LAUNCH_M(false, false);
 #undef RT_LAUNCH_M
-#undef RT_LAUNCH_R
+#undef RT_LAUNCH_F
 #undef RT_LAUNCH_Q
 #undef RT_LAUNCH
     return hipGetLastError();

@@ -75,14 +75,52 @@ def test_stratified_sample_of_the_frame_agrees_with_the_checker(frames, oracle, 
     assert (np.abs(got - want).max(axis=2) > 1e-5).mean() < 0.02
 
 
+def test_cornell_frame_at_1000_samples_adds_up_and_reassembles(api):
+    """The Cornell configuration at its own size and sample count (1920x1080, 1000 samples per
+    pixel, depth 50): the frame equals the sum of two windows of its samples taken as integer sums
+    (a sample-split over ranks) bit for bit, reassembles bit for bit from 8 interleaved row-tile
+    shards (a tile split over ranks), and does not depend on the tile shape; the 32.32 accumulators
+    and the 32-bit unit count of a tile are run at the sample count the configuration names."""
+    from raytrace_amd import scene as S
+    P = api.Context.params
+    Wc, Hc, spp = 1920, 1080, 1000
+    flat = S.flatten(S.cornell_scene(), background=S.RT_BG_SOLID, bg_color=(0, 0, 0))
+    c = api.Context(0)
+    c.upload_scene(flat)
+    c.set_camera(**S.cornell_camera(float(np.float32(Wc / Hc))).desc())
+    ref = c.render_host(P(Wc, Hc, spp, 50, 1))
+    st = c.stats()
+    assert (ref[..., 3] == spp).all() and np.isfinite(ref).all() and st["samples"] == Wc * Hc * spp
+    assert ref[..., :3].max() > 0 and 3.0 < st["rays"] / st["samples"] < 4.0
+    whole = c.render_host(P(Wc, Hc, spp, 50, 1, flags=api.RT_FLAG_FIXED_SUMS))
+    assert np.array_equal((whole[..., :3].astype(np.float64) * 2.0 ** -32).astype(np.float32), ref[..., :3])
+    total = c.render_host(P(Wc, Hc, 437, 50, 1, sample_begin=0, flags=api.RT_FLAG_FIXED_SUMS))
+    rays = c.stats()["rays"]
+    total += c.render_host(P(Wc, Hc, spp - 437, 50, 1, sample_begin=437, flags=api.RT_FLAG_FIXED_SUMS))
+    rays += c.stats()["rays"]
+    assert np.array_equal(total, whole) and rays == st["rays"]
+    del total, whole
+    out = np.zeros_like(ref)
+    rays = 0
+    for g in range(8):
+        part = c.render_host(P(Wc, Hc, spp, 50, 1, tiles=(4, g, 8)))
+        rays += c.stats()["rays"]
+        out[[r for t in range(g, Hc // 4, 8) for r in range(4 * t, 4 * t + 4)]] = part
+    assert np.array_equal(out, ref) and rays == st["rays"]
+    assert np.array_equal(c.render_host(P(Wc, Hc, spp, 50, 1, lanes_per_pixel=32)), ref)
+    c.close()
+
+
 def test_million_sphere_frame_does_not_depend_on_the_builder(api):
-    """The 10^6-sphere configuration at its full 3840x2160 size (2 samples per pixel here): the
-    host-built and the GPU-built tree give the same bits, and a sample of primary rays hits what
-    the device's own linear scan over all 10^6 spheres hits."""
+    """The 10^6-sphere configuration at its own size and sample count (3840x2160, 64 samples per
+    pixel, depth 50): the host-built and the GPU-built tree give the same bits and the same ray
+    count, and a sample of primary rays hits what the device's own linear scan over all 10^6
+    spheres hits.  (The scene's generator, camera and textures meet the double-precision checker
+    on a crop of the scene in test_gpu_scenes.py.)"""
     from raytrace_amd import scene as S
     flat = S.stress_flat(1_000_000)
     cam = S.stress_camera(float(np.float32(3840 / 2160))).desc()
-    imgs, hits = [], []
+    imgs, hits, counts = [], [], []
     rng = np.random.default_rng(3)
     rays = np.concatenate([np.tile([0, 60, -120], (512, 1)), np.tile([0, -0.45, 1], (512, 1)) + 0.3 * rng.normal(size=(512, 3))], 1).astype(np.float32)
     for accel in (api.RT_ACCEL_BVH, api.RT_ACCEL_BVH_DEVICE, api.RT_ACCEL_LIST):
@@ -90,11 +128,13 @@ def test_million_sphere_frame_does_not_depend_on_the_builder(api):
         c.upload_scene(flat, accel=accel)
         c.set_camera(**cam)
         if accel != api.RT_ACCEL_LIST:
-            imgs.append(c.render_host(api.Context.params(3840, 2160, 2, 50, 1)))
-            assert c.stats()["bvh_depth"] <= 46
+            imgs.append(c.render_host(api.Context.params(3840, 2160, 64, 50, 1)))
+            counts.append(c.stats()["rays"])
+            assert c.stats()["bvh_depth"] <= 46 and c.stats()["samples"] == 3840 * 2160 * 64
         hits.append(c.trace_primary(rays))
         c.close()
-    assert np.array_equal(imgs[0], imgs[1]) and imgs[0][..., :3].max() > 0
+    assert np.array_equal(imgs[0], imgs[1]) and imgs[0][..., :3].max() > 0 and counts[0] == counts[1]
+    assert (imgs[0][..., 3] == 64).all() and np.isfinite(imgs[0]).all()
     for f in ("id", "t", "front_face"):
         assert np.array_equal(hits[0][f], hits[2][f]) and np.array_equal(hits[1][f], hits[2][f]), f
     assert (hits[2]["id"] >= 0).mean() > 0.5

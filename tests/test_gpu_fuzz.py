@@ -121,7 +121,8 @@ def test_random_scene(seed, oracle):
             # a normal moves by (shift of the hit point) / radius, and the hit point of a grazing ray by
             # (shift of the surface: 1e-7 of its coordinates, the rounding of the records) / cos
             # (scene 545253 of the generator: cos 1.6e-3, t off by 1.4e-6 of itself, the normal by 6.7e-5)
-            assert (np.abs(hits["n"][ok] - want["n"][ok]).max(axis=1) <= 1e-5 + 2e-7 / cos[ok]).all()
+            # that term only where a ray grazes (cos < 1e-2: up to 2e-4 at the 1e-3 the rays are kept above); elsewhere 1e-5
+            assert (np.abs(hits["n"][ok] - want["n"][ok]).max(axis=1) <= 1e-5 + np.where(cos[ok] < 1e-2, 2e-7 / cos[ok], 0.0)).all()
             assert np.array_equal(hits["front_face"][ok], want["front"][ok])
         img = ctx.render_host(api.Context.params(W, H, spp, 50, 77 + seed))
         st = ctx.stats()
@@ -213,7 +214,9 @@ def test_random_sphere_field(seed, oracle):
         rays.append(np.concatenate([o, dvec]))
     rays = np.asarray(rays, np.float64).astype(np.float32).astype(np.float64)
     want = oracle.trace(flat, rays, t_min=0.001)
-    W, H, spp, depth = 60, 40, 4, int(rng.choice([3, 50]))
+    # depth limits: 3 and 8, where single precision decides every branch of a path like the double-precision
+    # checker (tools/field_case.py: no pixel differs up to 8) and the strict bounds hold, and 50
+    W, H, spp, depth = 60, 40, 4, (50 if seed in _KEPT_FIELDS else int(rng.choice([3, 8, 50])))
     sums, n_rays = oracle.render(flat, cd, W, H, spp, depth, 9 + seed, threads=8)
     first = None
     for accel in (api.RT_ACCEL_BVH, api.RT_ACCEL_BVH_DEVICE, api.RT_ACCEL_LIST):
@@ -236,7 +239,8 @@ def test_random_sphere_field(seed, oracle):
         ok = ~bad & (want["id"] >= 0) & (cos > 1e-3)
         rel = np.abs(hits["t"][ok] - want["t"][ok]) / np.abs(want["t"][ok])
         assert rel.max() <= 1e-5, (accel, float(rel.max()))
-        assert (np.abs(hits["n"][ok] - want["n"][ok]).max(axis=1) <= 1e-5 + 2e-7 / cos[ok]).all()   # (grazing rays: as in test_random_scene)
+        # (grazing rays, cos < 1e-2 only: as in test_random_scene)
+        assert (np.abs(hits["n"][ok] - want["n"][ok]).max(axis=1) <= 1e-5 + np.where(cos[ok] < 1e-2, 2e-7 / cos[ok], 0.0)).all()
         img = ctx.render_host(api.Context.params(W, H, spp, depth, 9 + seed))
         st = ctx.stats()
         if accel == api.RT_ACCEL_BVH:
@@ -261,7 +265,9 @@ def test_random_sphere_field(seed, oracle):
         # precision paths part after seven or eight specular bounces (measured: no pixel differs up
         # to depth limit 2, 6 % differ at 50; ray counts over 400 scenes centred on zero with a
         # relative sd of 1e-3 at 27 648 samples, largest 4.9e-3; this test's 9 600 samples scatter twice as much)
-        assert abs(st["rays"] - n_rays) <= max(40, (4e-3 if depth <= 3 else 3e-2) * n_rays), (accel, st["rays"], n_rays)
+        assert abs(st["rays"] - n_rays) <= max(40, (4e-3 if depth <= 8 else 3e-2) * n_rays), (accel, depth, st["rays"], n_rays)
         peak = max(1.0, float(sums.max() / spp))
-        # (at depth limit 50 one scene in 37 000 reached 0.066 of the peak: tools/field_case.py shows it by depth limit)
-        assert np.sqrt(np.mean((img[..., :3] / spp - sums / spp) ** 2)) <= (0.02 if depth <= 3 else 0.09) * peak
+        # (at depth limit 50 one scene in 37 000 reached 0.066 of the peak, the kept one: tools/field_case.py shows
+        # it by depth limit; the wider bound is that scene's alone)
+        bound = 0.02 if depth <= 8 else (0.09 if seed in _KEPT_FIELDS else 0.06)
+        assert np.sqrt(np.mean((img[..., :3] / spp - sums / spp) ** 2)) <= bound * peak, (accel, depth)

@@ -288,6 +288,75 @@ def test_params_layouts_and_tuning_fields(api, rtiow_flat):
         assert ctx.stats()["rays"] == rays
     with pytest.raises(api.RtError):
         ctx.render_host(P(W, H, spp, 50, 2, traversal_slice=-2))
+    # out of range is an error, not a silent clamp: a slice beyond 65534 steps, a quorum beyond a wavefront's 64 lanes
+    for kw in (dict(traversal_slice=65535), dict(leaf_quorum=65), dict(leaf_quorum=2 ** 31 - 1), dict(leaf_quorum=-2)):
+        with pytest.raises(api.RtError) as e:
+            ctx.render_host(P(W, H, spp, 50, 2, **kw))
+        assert e.value.code == api.RT_ERR_INVALID, kw
+    assert np.array_equal(ctx.render_host(P(W, H, spp, 50, 2, traversal_slice=65534, leaf_quorum=64)), ref)
+    ctx.close()
+
+
+def test_stats_are_written_up_to_the_callers_struct_size(api, rtiow_flat):
+    """rt_get_stats writes no more than the caller's struct_size (so rt_stats may grow at its end), and
+    refuses a struct without one."""
+    ctx = api.Context(0)
+    ctx.upload_scene(rtiow_flat)
+    ctx.set_camera(**CAM)
+    ctx.render_host(api.Context.params(64, 48, 4, 50, 2))
+    full = ctx.stats()
+    assert full["rays"] > 64 * 48 * 4 and full["struct_size"] == ctypes.sizeof(api.Stats)
+    first = api.Stats.bvh_coarse_nodes.offset + 4                   # the struct as first published with a size
+    buf = (ctypes.c_uint8 * (ctypes.sizeof(api.Stats) + 64))()
+    ctypes.memset(buf, 0xAB, len(buf))
+    st = api.Stats.from_buffer(buf)
+    st.struct_size = first
+    assert api.lib().rt_get_stats(ctx._h, ctypes.byref(st)) == api.RT_OK
+    assert st.rays == full["rays"] and st.bvh_depth == full["bvh_depth"] and st.struct_size == first
+    assert all(b == 0xAB for b in bytes(buf)[first:])               # nothing behind the caller's struct was touched
+    for bad in (0, 8, first - 4):
+        st.struct_size = bad
+        assert api.lib().rt_get_stats(ctx._h, ctypes.byref(st)) == api.RT_ERR_INVALID
+    st.struct_size = len(buf)                                       # a newer caller: only what this library knows is written
+    assert api.lib().rt_get_stats(ctx._h, ctypes.byref(st)) == api.RT_OK and st.struct_size == ctypes.sizeof(api.Stats)
+    assert all(b == 0xAB for b in bytes(buf)[ctypes.sizeof(api.Stats):])
+    ctx.close()
+
+
+# ---- range of a pixel's sum (32.32 fixed point against main.cc:121's double) --------------------------------------------------
+
+def test_pixel_sums_are_refused_before_they_can_wrap(api, S):
+    """An emitter of 10^7 in front of the camera: 256 samples sum to 2.56e9 < 2^32 and the pixel holds
+    exactly that; 512 samples could reach 5.12e9 >= 2^32 and are refused with RT_ERR_UNSUPPORTED
+    (the reference's double sum does not wrap; a silent wrap would)."""
+    w = S.sceneobject_list()
+    w.add(S.xy_rect(-2, 2, -2, 2, 0.0, S.diffuse_light((1.0e7, 0.5e7, 10.0))))
+    flat = S.flatten(w, background=S.RT_BG_SOLID, bg_color=(0, 0, 0))
+    cam = dict(lookfrom=(0, 0, 3), lookat=(0, 0, 0), vup=(0, 1, 0), vfov=20.0, aspect=1.0, aperture=0.0, focus_dist=3.0)
+    ctx = api.Context(0)
+    ctx.upload_scene(flat)
+    ctx.set_camera(**cam)
+    P = api.Context.params
+    img = ctx.render_host(P(16, 16, 256, 5, 1))
+    assert (img[..., 0] == np.float32(256 * 1.0e7)).all() and (img[..., 1] == np.float32(256 * 0.5e7)).all() and (img[..., 2] == 2560.0).all()
+    assert (ctx.render_host(P(16, 16, 429, 5, 1))[..., 0] == np.float32(429 * 1.0e7)).all()       # 4.29e9 < 2^32
+    for kw in (dict(spp=512), dict(spp=430), dict(spp=30, sample_begin=400)):
+        with pytest.raises(api.RtError) as e:
+            ctx.render_host(P(16, 16, kw["spp"], 5, 1, sample_begin=kw.get("sample_begin", 0)))
+        assert e.value.code == api.RT_ERR_UNSUPPORTED and "2^32" in str(e.value), kw
+    # the same test sees a bright solid background and a bright texture
+    dim = S.sceneobject_list()
+    dim.add(S.sphere((0, 0, 0), 0.5, S.lambertian((0.5, 0.5, 0.5))))
+    ctx.upload_scene(S.flatten(dim, background=S.RT_BG_SOLID, bg_color=(3.0e7, 0, 0)))
+    with pytest.raises(api.RtError):
+        ctx.render_host(P(16, 16, 512, 5, 1))
+    assert np.isfinite(ctx.render_host(P(16, 16, 128, 5, 1))).all()
+    w3 = S.sceneobject_list()
+    w3.add(S.xy_rect(-2, 2, -2, 2, 0.0, S.diffuse_light(S.checker_texture((1.0, 1.0, 1.0), (2.0e7, 0.0, 0.0)))))
+    ctx.upload_scene(S.flatten(w3, background=S.RT_BG_SOLID, bg_color=(0, 0, 0)))
+    with pytest.raises(api.RtError):
+        ctx.render_host(P(16, 16, 256, 5, 1))
+    assert np.isfinite(ctx.render_host(P(16, 16, 128, 5, 1))).all()
     ctx.close()
 
 

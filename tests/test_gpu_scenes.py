@@ -363,3 +363,83 @@ def test_invalid_scenes_are_rejected(api, S):
     with pytest.raises(api.RtError):
         ctx.upload_scene(flat)
     ctx.close()
+
+
+# ---- the BVH stress scene itself (10^6 spheres in the bench; 2 x 10^4 here so the checker can scan it) ----
+
+def _stress_crop(S):
+    """The part of the 10^6-sphere scene of the bench that the lower half of its frame looks at: the
+    same spheres, materials and textures at the scene's own density (some 2.5 x 10^4 spheres, which the
+    checker's linear scan can afford; rays that leave the crop see the sky instead of the rest)."""
+    import dataclasses
+    full = S.stress_flat(1_000_000)
+    g = full.prim_geom
+    keep = (np.abs(g[:, 0]) < 70) & (g[:, 2] > -115) & (g[:, 2] < 110)
+    keep_mat = np.unique(full.prim_mat[keep])
+    remap = -np.ones(full.mat_type.shape[0], np.int64)
+    remap[keep_mat] = np.arange(keep_mat.shape[0])
+    return dataclasses.replace(full, prim_type=full.prim_type[keep], prim_geom=g[keep], prim_mat=remap[full.prim_mat[keep]].astype(np.int32),
+                               mat_type=full.mat_type[keep_mat], mat_param=full.mat_param[keep_mat], mat_tex=full.mat_tex[keep_mat])
+
+
+def test_stress_scene_against_the_restatement(api, S, oracle):
+    """Generator and camera of the 10^6-sphere configuration against the double-precision linear
+    scan: closest hits with surface coordinates of 3 000 camera rays, and a 96x54 frame at 8
+    samples per pixel under the same keyed stream, on either builder's tree (bounds of
+    test_textured_scene: texel and checker-cell lookups flip where float and double disagree on a
+    cell edge)."""
+    flat = _stress_crop(S)
+    assert 15_000 < flat.n_prims < 40_000
+    used = flat.tex_type[flat.mat_tex[flat.mat_tex >= 0]]
+    assert (used == S.RT_TEX_IMAGE).any() and (used == S.RT_TEX_CHECKER).any()
+    cam = S.stress_camera(float(np.float32(96 / 54))).desc()
+    cd = oracle.camera(**cam)
+    rng = np.random.default_rng(9)
+    rays = _f32(np.array([oracle.get_ray(cd, rng.random(), 0.6 * rng.random(), 5, k, 0)[0] for k in range(3000)]))
+    want = oracle.trace(flat, rays)
+    assert (want["id"] >= 0).mean() > 0.3
+    textured = flat.mat_tex[flat.prim_mat[want["id"][want["id"] >= 0]]] >= 0
+    assert textured.sum() > 20
+    W, H, spp = 96, 54, 8
+    sums, rays_n = oracle.render(flat, cd, W, H, spp, 50, 17, threads=8)
+    for accel in (api.RT_ACCEL_BVH, api.RT_ACCEL_BVH_DEVICE):
+        ctx = api.Context(0)
+        ctx.upload_scene(flat, accel=accel)
+        ctx.set_camera(**cam)
+        _check_hits(ctx.trace_primary(rays), want, uv_abs=2e-5, allow_id_mismatch=2)
+        img = ctx.render_host(api.Context.params(W, H, spp, 50, 17))
+        assert _rmse(img, sums, spp) <= 0.02, _rmse(img, sums, spp)
+        assert abs(ctx.stats()["rays"] - rays_n) / rays_n < 0.005
+        ctx.close()
+
+
+# ---- kernels built for what a scene holds against the kernel that carries every feature ---------------
+
+@pytest.mark.parametrize("which", ["spheres", "rects", "textures", "rects+textures"])
+def test_specialised_kernels_render_the_general_kernels_frame(api, S, which):
+    """A scene of plainly coloured spheres, a room of rects, a field of textured spheres and a
+    textured room each run in a kernel without the code of the features they lack
+    (RT_FLAG_ALL_FEATURES picks the kernel with all of it): same bits, same ray count, under the
+    tree walk in LDS, the walk out of HBM and the scan."""
+    W, H, spp = 160, 90, 8
+    if which == "spheres":
+        flat, cam = S.flatten(S.rtiow_scene()), S.rtiow_camera(float(np.float32(W / H))).desc()
+    elif which == "rects":
+        flat, cam = S.flatten(S.cornell_scene(), background=S.RT_BG_SOLID, bg_color=(0, 0, 0)), S.cornell_camera(float(np.float32(W / H))).desc()
+    elif which == "textures":
+        flat, cam = S.stress_flat(5000), S.stress_camera(float(np.float32(W / H))).desc()
+    else:
+        flat, cam = S.flatten(_textured_world(S)), dict(lookfrom=(0, 2.5, 9), lookat=(0, 1, 0), vup=(0, 1, 0), vfov=35.0,
+                                                        aspect=float(np.float32(W / H)), aperture=0.05, focus_dist=9.0)
+    for accel in (api.RT_ACCEL_BVH, api.RT_ACCEL_LIST):
+        ctx = api.Context(0)
+        ctx.upload_scene(flat, accel=accel)
+        ctx.set_camera(**cam)
+        for flags in (0, api.RT_FLAG_NO_LDS_SCENE, api.RT_FLAG_NO_LDS_SCENE | api.RT_FLAG_FLOAT_NODES):
+            for kw in ({}, {"traversal_slice": 8}):
+                a = ctx.render_host(api.Context.params(W, H, spp, 50, 5, flags=flags, **kw))
+                ra = ctx.stats()["rays"]
+                b = ctx.render_host(api.Context.params(W, H, spp, 50, 5, flags=flags | api.RT_FLAG_ALL_FEATURES, **kw))
+                assert np.array_equal(a, b) and ra == ctx.stats()["rays"], (which, accel, flags, kw)
+            assert a[..., :3].max() > 0
+        ctx.close()

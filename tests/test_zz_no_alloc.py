@@ -71,3 +71,37 @@ def test_noalloc_trace_limits(rtiow_flat):
     few = ctx.trace_primary(rays[n_max - 7: n_max], noalloc=True)
     assert _same(few, full[n_max - 7:])
     ctx.close()
+
+
+def test_noalloc_trace_from_two_threads_with_a_context_each(rtiow_flat):
+    """Two host threads, each with its own context on the same GPU (the way a sequence driver or a
+    per-thread worker holds them), call the entry point at the same time: the GPU's one staging array
+    is handed from call to call inside the library, so every answer equals rt_trace_primary's."""
+    import threading
+    from raytrace_amd import api
+    g = load_golden("primary_rays.npz")
+    rays = np.ascontiguousarray(g["rays"], np.float32).reshape(-1, 6)
+    t_min = float(g["t_min"])
+    sets = [rays, rays[::-1].copy()]                                 # different rays per thread: a mix-up would show
+    ctxs, wants = [], []
+    for k in range(2):
+        c = api.Context(0)
+        c.upload_scene(rtiow_flat, accel=api.RT_ACCEL_BVH if k == 0 else api.RT_ACCEL_LIST)
+        ctxs.append(c)
+        wants.append(c.trace_primary(sets[k], t_min))
+    assert not _same(wants[0], wants[1])
+    bad = []
+
+    def work(k):
+        for _ in range(40):
+            if not _same(ctxs[k].trace_primary(sets[k], t_min, noalloc=True), wants[k]):
+                bad.append(k)
+
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not bad
+    for c in ctxs:
+        c.close()

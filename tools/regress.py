@@ -1,6 +1,8 @@
 """Frame times of every kernel family on fixed scenes, one launch at a time: the table a change to the
 kernels is held against besides the four bench configurations (a change made for one scene has cost
-another its speed before).  usage: python tools/regress.py [out.json]"""
+another its speed before), with a digest of every frame: two builds whose digests agree render the same
+bits.  usage: python tools/regress.py [--lib other/librt_amd.so] [--quick] [out.json]"""
+import hashlib
 import json
 import os
 import sys
@@ -9,6 +11,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np                                # noqa: E402
 import torch                                      # noqa: E402
 from raytrace_amd import api, scene as S          # noqa: E402
+
+ARGS = sys.argv[1:]
+if "--lib" in ARGS:                               # another build of the library (same-box A/B)
+    api.LIB_PATH = os.path.abspath(ARGS[ARGS.index("--lib") + 1])
+    del ARGS[ARGS.index("--lib"):ARGS.index("--lib") + 2]
+QUICK = "--quick" in ARGS                         # without the rows that take seconds each
+if QUICK:
+    ARGS.remove("--quick")
 
 A = 16 / 9
 RTIOW_CAM = S.rtiow_camera(A).desc()
@@ -29,9 +39,11 @@ def measure(name, flat, cam, W, H, spp, depth=50, accel=api.RT_ACCEL_AUTO, flags
         ctx.render(api.Context.params(W, H, spp, depth, 1, flags=flags, **kw), buf.data_ptr())
         st = ctx.stats()
         best = st if best is None or st["kernel_ms"] < best["kernel_ms"] else best
+    digest = hashlib.sha1(buf.cpu().numpy().tobytes()).hexdigest()[:12]
     rows.append({"case": name, "frame": f"{W}x{H}@{spp}", "kernel_ms": round(best["kernel_ms"], 3),
-                 "mrays_s": round(best["rays"] / best["kernel_ms"] / 1e3, 1), "bvh_depth": best["bvh_depth"]})
-    print(f"{name:58s} {W}x{H}@{spp:<5d} {best['kernel_ms']:9.3f} ms {best['rays'] / best['kernel_ms'] / 1e3:9.1f} Mrays/s", flush=True)
+                 "mrays_s": round(best["rays"] / best["kernel_ms"] / 1e3, 1), "bvh_depth": best["bvh_depth"],
+                 "rays": best["rays"], "digest": digest})
+    print(f"{name:58s} {W}x{H}@{spp:<5d} {best['kernel_ms']:9.3f} ms {best['rays'] / best['kernel_ms'] / 1e3:9.1f} Mrays/s  {digest}", flush=True)
     if own:
         ctx.close()
     return ctx
@@ -53,6 +65,8 @@ measure("rtiow, GPU-built tree", rtiow, RTIOW_CAM, 1920, 1080, 100, accel=api.RT
 
 cornell = S.flatten(S.cornell_scene(), background=S.RT_BG_SOLID)
 measure("cornell (scan of 2 spheres from LDS + 6 rects)", cornell, S.cornell_camera(A).desc(), 1920, 1080, 100)
+if not QUICK:
+    measure("cornell at the sample count of configs[2]", cornell, S.cornell_camera(A).desc(), 1920, 1080, 1000)
 boxes = S.flatten(S.cornell_boxes_scene(), background=S.RT_BG_SOLID)
 measure("cornell with two turned boxes (instance rects)", boxes, S.cornell_camera(A).desc(), 1920, 1080, 100)
 sky = S.flatten(S.skybox_scene(), background=S.RT_BG_SOLID)
@@ -64,10 +78,12 @@ for n, (W, H, spp) in ((20_000, (1920, 1080, 64)), (100_000, (1920, 1080, 64)), 
     c = api.Context(0)
     c.upload_scene(flat, accel=api.RT_ACCEL_BVH)
     measure(f"{n} spheres, host tree, 32-byte nodes", flat, cam, W, H, spp, ctx=c)
+    if n == 1_000_000 and not QUICK:
+        measure(f"{n} spheres at the sample count of configs[3]", flat, cam, W, H, 64, ctx=c)
     measure(f"{n} spheres, host tree, 64-byte float nodes", flat, cam, W, H, spp, ctx=c, flags=api.RT_FLAG_FLOAT_NODES)
     c.close()
     measure(f"{n} spheres, GPU-built tree", flat, cam, W, H, spp, accel=api.RT_ACCEL_BVH_DEVICE)
 
-if len(sys.argv) > 1:
-    with open(sys.argv[1], "w") as f:
+if ARGS:
+    with open(ARGS[0], "w") as f:
         json.dump(rows, f, indent=1)
