@@ -622,6 +622,7 @@ int rt_upload_scene(rt_context* ctx, const rt_scene_desc* d) {
         for (const rt::DWide& w : wide) if (w.xform) instances = true;
     }
     if (instances) s.has_textures |= 2;
+    for (const rt::DMaterial& m : mats) if (m.type == RT_DIFFUSE_LIGHT || m.type == RT_LAMBERTIAN_BG) s.has_textures |= 4;
     s.n_wide = (int)wide.size();
     s.n_rects = (int)rects.size();
     s.background = d->background;

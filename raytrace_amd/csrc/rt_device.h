@@ -74,7 +74,7 @@ struct DScene {
     int use_bvh;          // 0: scan all ordinary spheres in order
     int ids_fit_16;       // every list position and material index is below 65536
     int has_textures;     // bit 0: some material reads a texture; bit 1: some rect, or some sphere whose material reads a
-                          // texture, stands under an instance transform (one word: the order and number of the fields
+                          // texture, stands under an instance transform; bit 2: some material emits (one word: the order and number of the fields
                           // of a kernel-argument struct move the register allocation of every kernel)
     const DWide* wide;
     int n_wide;

@@ -425,7 +425,12 @@ __device__ __forceinline__ RayN normalise(V3 d, float t_min) {
 //   kFeatRects      rects (cuda/rect.h:29-52)
 //   kFeatTextures   some material reads a texture (cuda/texture.h:17-78): surface coordinates, texture_value
 //   kFeatInstances  some primitive stands under rotate_y / translate (cuda/sceneobject.h:31-109)
-constexpr int kFeatRects = 1, kFeatTextures = 2, kFeatInstances = 4, kFeatAll = 7;
+//   kFeatEmitters   some material emits (cuda/material.h:33-47,103-119): without one a path's radiance is
+//                   its throughput times the background where it leaves the scene, and the running sum
+//                   of emitted light (three registers for the whole path) is not kept
+constexpr int kFeatRects = 1, kFeatTextures = 2, kFeatInstances = 4, kFeatEmitters = 8, kFeatAll = 15;
+constexpr int kFeatRoom = kFeatRects | kFeatEmitters;   // the combinations kernels are built for besides none and all:
+constexpr int kFeatTexturedRoom = kFeatRoom | kFeatTextures;   // a room with its light, the same with textures, kFeatTextures alone
 template <bool COUNT, int FEAT>
 __device__ __forceinline__ void hit_always(const DScene& sc, V3 o, V3 d, const RayN& rn, float t_min, Origin from,
                                            Cand& best, Counters& cn) {
@@ -927,12 +932,26 @@ __device__ __forceinline__ V3 in_unit_sphere(uint4 w) {
     if (dot(p, p) >= 1.0f) {
         Xo g; g.s0 = w.x; g.s1 = w.y; g.s2 = w.z; g.s3 = w.w;
         xo_step(g);
+#ifdef RT_REJECT_PAIRS
+        // two attempts per trip of the loop (the second one's answer is used only if the first is
+        // rejected: the same point as one attempt per trip, in half the trips)
+        for (int i = 0; i < 128; i++) {
+            xo_step(g);
+            const V3 a = mk(pm1(g.s0 - g.s3), pm1(g.s1 + g.s2), pm1(g.s0 + g.s3));
+            xo_step(g);
+            const V3 b = mk(pm1(g.s0 - g.s3), pm1(g.s1 + g.s2), pm1(g.s0 + g.s3));
+            const bool ok_a = !(dot(a, a) >= 1.0f), ok_b = !(dot(b, b) >= 1.0f);
+            p = ok_a ? a : b;
+            if (ok_a || ok_b) break;
+        }
+#else
         for (int i = 0; i < 256; i++) {
             xo_step(g);
             float z = pm1(g.s0 + g.s3), y = pm1(g.s1 + g.s2), x = pm1(g.s0 - g.s3);
             p = mk(x, y, z);
             if (!(dot(p, p) >= 1.0f)) break;
         }
+#endif
     }
     return p;
 }
@@ -945,10 +964,11 @@ __device__ __forceinline__ V3 reflect(V3 v, V3 n) { return madd(v, -2.0f * dot(v
 // Returns true when the path continues along (so, sd).  `emitted` is always written.
 // `w` is the Philox block of the path's current scatter segment; `rs` a point in the unit sphere
 // drawn from it (both materials that need one read the same draws, so it is drawn once).
+template <bool EMIT>
 __device__ __forceinline__ bool scatter(const DScene& sc, const DMaterial& m, V3 ud, const Rec& r, uint4 w, V3 rs,
                                         V3& att, V3& sd, V3& emitted) {
     emitted = mk(0.0f, 0.0f, 0.0f);
-    switch (m.type) {
+    switch (EMIT ? m.type : (m.type > 2 ? 0 : m.type)) {       // (no emitters in the scene: the upload says so)
     case 0: {                                          // lambertian, material.h:21-32
         V3 s = rs;
         V3 uvec = __builtin_amdgcn_rsqf(dot(s, s)) * s;   // vec3.h:139
@@ -986,7 +1006,7 @@ __device__ __forceinline__ bool scatter(const DScene& sc, const DMaterial& m, V3
         return true;
     }
     default:                                           // diffuse_light, lambertian_bg
-        emitted = material_color(sc, m, r);
+        if constexpr (EMIT) emitted = material_color(sc, m, r);
         att = mk(0.0f, 0.0f, 0.0f);
         sd = mk(0.0f, 0.0f, 0.0f);
         return false;
@@ -1047,11 +1067,13 @@ __device__ __forceinline__ unsigned long long clk() { return __builtin_amdgcn_s_
 template <bool COUNT, int FEAT, class G>
 __device__ __forceinline__ bool shade(const DScene& sc, const G& geo, const DRender& rp, const Cand& c, const Key& key, int depth,
                                       bool refine, const RayN& rn, V3& o, V3& d, V3& T, V3& L, Origin& from, Counters& cn) {
+    constexpr bool RECTS = (FEAT & kFeatRects) != 0, TEX = (FEAT & kFeatTextures) != 0, EMIT = (FEAT & kFeatEmitters) != 0;
+    // without emitters nothing is added along the way: L is written where a path ends, and only there
+    if constexpr (!EMIT) L = mk(0.0f, 0.0f, 0.0f);
     if (c.kind < 0) {
         L = L + T * background(sc, rn.dh);
         return true;
     }
-    constexpr bool RECTS = (FEAT & kFeatRects) != 0, TEX = (FEAT & kFeatTextures) != 0;
     // the loads the record and the material need go out first; the Philox block below is pure
     // arithmetic and runs while they are in flight
     const int mat = c.kind == 0 ? geo.mat(c.idx) : ((!RECTS || c.kind == 1) ? sc.wide[c.idx].mat : sc.rects[c.idx].mat);
@@ -1068,8 +1090,8 @@ __device__ __forceinline__ bool shade(const DScene& sc, const G& geo, const DRen
     if (COUNT) cn.shade++;
     V3 rs = mk(0.0f, 0.0f, 0.0f);
     if (m.type == 0 || (m.type == 1 && m.fuzz > 0.0f)) rs = in_unit_sphere(w);
-    bool cont = scatter(sc, m, rn.dh, r, w, rs, att, sd, em);
-    L = L + T * em;
+    bool cont = scatter<EMIT>(sc, m, rn.dh, r, w, rs, att, sd, em);
+    if constexpr (EMIT) L = L + T * em;
     T = T * att;
     o = r.p;
     d = sd;
@@ -1499,7 +1521,7 @@ hipError_t launch_render(const DScene& sc, const DCamera& cam, const DRender& rp
         int steps = r.slice & 0xffff, share = (r.slice >> 16) & 0xff;
         const bool chosen = steps == 0xffff;
         if (chosen) steps = sc.bvh_depth > 16 ? 64 : 0;
-        rounds = chosen && steps == 0 && share > 0 && sc.use_bvh && sc.n_rects == 0 && !sc.has_textures && (rp.flags & 256u) == 0u &&
+        rounds = chosen && steps == 0 && share > 0 && sc.use_bvh && sc.n_rects == 0 && !sc.has_textures && (rp.flags & 256u) == 0u &&   // (has_textures: any of its bits)
                  (in_lds || (sc.qnodes != nullptr && (rp.flags & 128u) == 0u));
         if (share == 255) share = steps > 0 ? kExitShare : kRoundShare;
         r.slice = (steps > 0 || rounds) ? (steps | (share << 16)) : 0;
@@ -1534,13 +1556,15 @@ hipError_t launch_render(const DScene& sc, const DCamera& cam, const DRender& rp
     // come with everything else (scenes of turned boxes are rooms with textures more often than not); the
     // counting and the phase-clock builds (diagnostics: their counts do not depend on it) exist without
     // any of it and with all of it
-    int feat = (sc.n_rects > 0 ? kFeatRects : 0) | ((sc.has_textures & 1) ? kFeatTextures : 0) | ((sc.has_textures & 2) ? kFeatInstances : 0);
+    int feat = (sc.n_rects > 0 ? kFeatRects : 0) | ((sc.has_textures & 1) ? kFeatTextures : 0) | ((sc.has_textures & 2) ? kFeatInstances : 0) |
+               ((sc.has_textures & 4) ? kFeatEmitters : 0);
     if ((feat & kFeatInstances) || ((count || prof) && feat != 0) || (rp.flags & 256u) != 0u) feat = kFeatAll;
+    else if (feat != 0 && feat != kFeatTextures) feat = (feat & kFeatTextures) ? kFeatTexturedRoom : kFeatRoom;   // the built combination that covers it
 #define RT_LAUNCH_Q(C, L, P, M, F) do { if (!L && M == 2 && quant && deep) RT_LAUNCH(C, L, P, M, F, ((!L && M == 2) ? 2 : 0)); \
         else if (!L && M != 0 && quant) RT_LAUNCH(C, L, P, M, F, ((!L && M != 0) ? 1 : 0)); else RT_LAUNCH(C, L, P, M, F, 0); } while (0)
 #define RT_LAUNCH_F(C, L, P, M) do { if (feat == 0) RT_LAUNCH_Q(C, L, P, M, 0); else if (feat == kFeatAll) RT_LAUNCH_Q(C, L, P, M, kFeatAll); \
-        else if constexpr (!C && !P) { if (feat == kFeatRects) RT_LAUNCH_Q(C, L, P, M, kFeatRects); else if (feat == kFeatTextures) RT_LAUNCH_Q(C, L, P, M, kFeatTextures); \
-                                       else RT_LAUNCH_Q(C, L, P, M, (kFeatRects | kFeatTextures)); } } while (0)
+        else if constexpr (!C && !P) { if (feat == kFeatRoom) RT_LAUNCH_Q(C, L, P, M, kFeatRoom); else if (feat == kFeatTextures) RT_LAUNCH_Q(C, L, P, M, kFeatTextures); \
+                                       else RT_LAUNCH_Q(C, L, P, M, kFeatTexturedRoom); } } while (0)
 #define RT_LAUNCH_M(C, P) do { \
         if (!sc.use_bvh) { if (in_lds) RT_LAUNCH_F(C, true, P, 0); else RT_LAUNCH_F(C, false, P, 0); } \
         else if (in_lds) { if (sliced) RT_LAUNCH_F(C, true, P, 2); else if (rounds) RT_LAUNCH(C, true, P, 3, 0, 0); else RT_LAUNCH_F(C, true, P, 1); } \

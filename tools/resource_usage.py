@@ -22,13 +22,13 @@ def main():
         def g(k):
             m = re.search(k + r": (\d+)", b)
             return int(m.group(1)) if m else -1
-        m = re.search(r"render_kernelILb(\d)ELb(\d)ELb(\d)ELi(\d)ELi(\d)ELi(\d)E", name)
+        m = re.search(r"render_kernelILb(\d)ELb(\d)ELb(\d)ELi(\d)ELi(\d+)ELi(\d)E", name)
         if not m:
             continue
         rows.append((tuple(int(x) for x in m.groups()), g("VGPRs"), g("VGPRs Spill"), g("SGPRs Spill"), g(r"ScratchSize \[bytes/lane\]"), g(r"Occupancy \[waves/SIMD\]")))
     print("COUNT LDS PROF MODE FEAT QUANT | VGPRs spilled sgpr-spilled scratch-bytes waves/SIMD")
     for key, v, sp, ss, sc, occ in sorted(rows):
-        print("  %d    %d    %d    %d    %d    %d   | %4d %5d %8d %10d %8d" % (*key, v, sp, ss, sc, occ))
+        print("  %d    %d    %d    %d   %2d    %d   | %4d %5d %8d %10d %8d" % (*key, v, sp, ss, sc, occ))
     print(len(rows), "render kernels")
 
 
