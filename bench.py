@@ -139,6 +139,51 @@ def lone_frames(name, device, stream_ptr, frames=3):
     return out
 
 
+def reconstruction_stage(device, stream_ptr):
+    """The low-to-high sample-count reconstruction stage on a frame of the camera path (1920x1080): guides +
+    a-trous passes on the 16-sample frame, against the 256-sample frame of the same camera.  Bandwidth-bound;
+    parity unpinned (the reference holds no code or output of such a stage), so the figure of merit is PSNR."""
+    import torch
+    from raytrace_amd import api
+    wl = Workload("c5")
+    W, H, low_spp, high_spp, passes = wl.W, wl.H, 16, wl.spp, 4
+    ctx = api.Context(device)
+    ctx.set_stream(stream_ptr)
+    ctx.upload_scene(wl.flat, accel=wl.accel)
+    cam, seed = wl.camera_of_step(1)
+    ctx.set_camera(**cam)
+    low, high, out = (torch.zeros((H, W, 4), dtype=torch.float32, device="cuda") for _ in range(3))
+    guides = torch.zeros((2, H, W, 4), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    ctx.render(api.Context.params(W, H, high_spp, wl.depth, seed), high.data_ptr())
+    ctx.render(api.Context.params(W, H, low_spp, wl.depth, seed), low.data_ptr())
+    low_ms = ctx.stats()["kernel_ms"]
+    g_ms, r_ms = [], []
+    for _ in range(5):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        ev[0].record()
+        ctx.render_guides(W, H, guides.data_ptr())
+        ev[1].record()
+        ctx.reconstruct(low.data_ptr(), guides.data_ptr(), W, H, out.data_ptr(), iterations=passes)
+        ev[2].record()
+        torch.cuda.synchronize()
+        g_ms.append(ev[0].elapsed_time(ev[1]))
+        r_ms.append(ev[1].elapsed_time(ev[2]))
+    ctx.close()
+
+    def psnr(a, spp):
+        shown = lambda x, n: torch.sqrt(torch.clamp(x[..., :3] / n, 0.0, 1.0))
+        return float(-10.0 * torch.log10(torch.mean((shown(a, spp) - shown(high, high_spp)) ** 2)))
+    g, r = min(g_ms), min(r_ms)
+    algo = W * H * (32 + 16 + passes * (36 + 16))       # demodulate (frame + albedo in, colour out) + per pass: colour, normal + distance, object in, colour out
+    return {"workload": f"{W}x{H}, frame 1 of the camera path: {low_spp}-sample frame reconstructed towards the {high_spp}-sample frame",
+            "low_frame_ms": low_ms, "guides_ms": g, "reconstruct_ms": r, "passes": passes,
+            "psnr_low_db": psnr(low, low_spp), "psnr_reconstructed_db": psnr(out, low_spp),
+            "roofline": {"bound": "hbm", "achieved": algo / (r * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": algo / (r * 1e-3) / 1e9 / PEAK_HBM_GBS, "algorithmic_bytes": algo},
+            "parity": "unpinned: the reference names the stage (README.md:7) and holds no code, weights or output of it"}
+
+
 class Workload:
     """Scene, camera and frame size of one --config."""
 
@@ -583,7 +628,8 @@ def main():
         del fbufs
         torch.cuda.empty_cache()
         sp = torch.cuda.current_stream().cuda_stream
-        other = {"c3": lone_frames("c3", device, sp, 3), "c4": lone_frames("c4", device, sp, 3), "c5": lone_frames("c5", device, sp, 1)}
+        other = {"c3": lone_frames("c3", device, sp, 3), "c4": lone_frames("c4", device, sp, 3), "c5": lone_frames("c5", device, sp, 1),
+                 "reconstruction": reconstruction_stage(device, sp)}
 
     if rank == 0:
         if not dist_on:

@@ -18,6 +18,8 @@
  *                                sceneobject_list.h:26-39  rt_trace_primary (+ rt_trace_primary_noalloc)
  *   write_color / output_image   color.h:9-26,
  *                                cuda/main.cu:358-383      rt_quantize
+ *   low / high frame pairs       cuda/main.cu:557-576,
+ *                                README.md:7               rt_render_guides + rt_reconstruct (no code in the reference)
  *   gpuErrchk                    cuda/main.cu:24-32        return codes + rt_last_error
  *
  * Conventions: every function returns RT_OK (0) or a negative rt_error; nothing exits or
@@ -242,6 +244,39 @@ int rt_quantize(rt_context* ctx, const float* rgba_device, int64_t n_pixels, int
  * n_pixels float4 (rgb = sum, or mean with mean != 0; a = samples), exactly as rt_render converts its own
  * sums.  Asynchronous on the context's stream. */
 int rt_resolve_sums(rt_context* ctx, const uint64_t* sums_device, int64_t n_pixels, int32_t mean, float* rgba_device);
+
+/* Low-to-high sample-count reconstruction.  The reference names such a stage as ongoing work (README.md:7:
+ * a learned upscaler "similar to DLSS") and lays out the frame pairs for it (cuda/main.cu:557-576: every frame
+ * once with few and once with many samples); it holds no code, weights or output of it, so these two entry
+ * points have no counterpart there to be identical to.  They turn the low frame of such a pair into an
+ * estimate of the high one:
+ *
+ * rt_render_guides: what the ray through the centre of every pixel (from the centre of the lens) hits first
+ *   under the context's scene and camera: two planes of width x height float4, rows bottom-up like the image;
+ *   plane 0 = (unit normal facing against the ray, distance t), plane 1 = (albedo r g b of the surface there --
+ *   texture value, emitted colour, white for a dielectric --, list position of the object as int32 bits).  A ray
+ *   that leaves the scene has normal 0, t 0, albedo 1, position -1.  Asynchronous on the context's stream.
+ *
+ * rt_reconstruct: the edge-avoiding a-trous wavelet transform (Dammertz, Sewtz, Hanika, Lensch, HPG 2010) of the
+ *   frame's mean radiance: `iterations` passes of a 5x5 B3-spline kernel whose taps stand 1, 2, 4, ... pixels
+ *   apart, a tap counting by how well it agrees with the centre pixel in first-hit object (equal or not),
+ *   normal (cosine to the power sigma_normal), distance (exp(-|t_p - t_q| / (sigma_depth t_p))) and colour
+ *   (exp(-|c_p - c_q|^2 / s^2), s = sigma_color halved from pass to pass), on colours divided by the first hit's
+ *   albedo (at least albedo_floor) so that texture detail is not blurred.  rgba_device: a frame as rt_render
+ *   leaves it (rgb = sum over a samples); rgba_out_device: the same convention (rgb = reconstructed mean x a); the
+ *   two may be the same buffer.  The context keeps two images of scratch memory, grown on demand.  params NULL =
+ *   defaults.  Asynchronous on the context's stream. */
+typedef struct rt_reconstruct_params {
+    uint32_t struct_size;        /* sizeof(rt_reconstruct_params) */
+    int32_t iterations;          /* 1 .. 8; 0 = default (4) */
+    float sigma_color;           /* 0 = default: 1.6 / sqrt(samples of the pixel) */
+    float sigma_normal;          /* 0 = default (16) */
+    float sigma_depth;           /* 0 = default (0.05) */
+    float albedo_floor;          /* 0 = default (0.02) */
+} rt_reconstruct_params;
+int rt_render_guides(rt_context* ctx, int32_t width, int32_t height, float* guides_device);
+int rt_reconstruct(rt_context* ctx, const float* rgba_device, const float* guides_device, int32_t width, int32_t height,
+                   const rt_reconstruct_params* params, float* rgba_out_device);
 
 /* Waits for the context's stream, then reports the last render.  out->struct_size must be set by the caller
  * to sizeof(rt_stats) of the header it was compiled against; a size smaller than the struct of version 0.3

@@ -20,7 +20,7 @@ RT_FLAG_ALL_FEATURES = 256
 
 EXPORTS = ["rt_create", "rt_destroy", "rt_set_stream", "rt_upload_scene", "rt_set_camera",
            "rt_shard_rows", "rt_render", "rt_render_host", "rt_trace_primary", "rt_trace_primary_noalloc", "rt_quantize",
-           "rt_resolve_sums", "rt_get_stats", "rt_last_error", "rt_version",
+           "rt_resolve_sums", "rt_render_guides", "rt_reconstruct", "rt_get_stats", "rt_last_error", "rt_version",
            "rt_decode_jpeg", "rt_load_jpeg_file", "rt_free_image", "rt_image_last_error", "rt_write_ppm"]
 
 
@@ -56,6 +56,11 @@ class RenderParams(C.Structure):
                 ("tile_step", C.c_int32), ("t_min", C.c_float), ("flags", C.c_uint32),
                 ("lanes_per_pixel", C.c_int32), ("traversal_slice", C.c_int32), ("leaf_quorum", C.c_int32),
                 ("stack_lds_entries", C.c_int32), ("traversal_exit_share", C.c_int32)]
+
+
+class ReconstructParams(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("iterations", C.c_int32), ("sigma_color", C.c_float),
+                ("sigma_normal", C.c_float), ("sigma_depth", C.c_float), ("albedo_floor", C.c_float)]
 
 
 class Hit(C.Structure):
@@ -112,6 +117,8 @@ def lib():
         L.rt_trace_primary_noalloc.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_void_p]
         L.rt_quantize.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]
         L.rt_resolve_sums.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]
+        L.rt_render_guides.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+        L.rt_reconstruct.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(ReconstructParams), C.c_void_p]
         L.rt_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
         L.rt_last_error.argtypes = [C.c_void_p]
         L.rt_last_error.restype = C.c_char_p
@@ -287,6 +294,20 @@ class Context:
         """RT_FLAG_FIXED_SUMS image (device) -> float4 image (device), as rt_render converts its own sums."""
         self._check(lib().rt_resolve_sums(self._h, C.c_void_p(sums_device_ptr), n_pixels, int(bool(mean)),
                                           C.c_void_p(rgba_device_ptr)))
+
+    def render_guides(self, width, height, guides_device_ptr):
+        """First-hit guides of the reconstruction stage into device memory: two planes of height x width
+        float4 (normal + distance; albedo + list position as int32 bits)."""
+        self._check(lib().rt_render_guides(self._h, width, height, C.c_void_p(guides_device_ptr)))
+
+    def reconstruct(self, rgba_device_ptr, guides_device_ptr, width, height, out_device_ptr, iterations=0, sigma_color=0.0,
+                    sigma_normal=0.0, sigma_depth=0.0, albedo_floor=0.0):
+        """Edge-avoiding a-trous reconstruction of a low-sample-count frame (rt_reconstruct); 0 = default."""
+        p = ReconstructParams()
+        p.struct_size = C.sizeof(ReconstructParams)
+        p.iterations, p.sigma_color, p.sigma_normal, p.sigma_depth, p.albedo_floor = iterations, sigma_color, sigma_normal, sigma_depth, albedo_floor
+        self._check(lib().rt_reconstruct(self._h, C.c_void_p(rgba_device_ptr), C.c_void_p(guides_device_ptr), width, height,
+                                         C.byref(p), C.c_void_p(out_device_ptr)))
 
     def stats(self):
         s = Stats()

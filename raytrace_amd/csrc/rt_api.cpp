@@ -45,6 +45,8 @@ struct rt_context {
     size_t staging_bytes = 0;
     unsigned char* trace_buf = nullptr;       // device copies of rays and hits for rt_trace_primary (grown on demand)
     size_t trace_rays = 0;                    // rays it holds
+    float4* recon_tmp = nullptr;              // two images of scratch for rt_reconstruct (grown on demand)
+    size_t recon_pixels = 0;
     unsigned char* noalloc = nullptr;         // this device's address of the fixed staging array of rt_trace_primary_noalloc
 };
 
@@ -296,6 +298,7 @@ void rt_destroy(rt_context* ctx) {
     if (ctx->staging) (void)hipFree(ctx->staging);
     if (ctx->trace_buf) (void)hipFree(ctx->trace_buf);
     if (ctx->stack_spill) (void)hipFree(ctx->stack_spill);
+    if (ctx->recon_tmp) (void)hipFree(ctx->recon_tmp);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
     delete ctx;
@@ -780,6 +783,53 @@ int rt_resolve_sums(rt_context* ctx, const uint64_t* sums_device, int64_t n_pixe
     }
     RT_HIP(ctx, rt::launch_resolve(reinterpret_cast<const unsigned long long*>(sums_device), n_pixels, mean != 0,
                                    reinterpret_cast<float4*>(rgba_device), ctx->stream));
+    return RT_OK;
+}
+
+int rt_render_guides(rt_context* ctx, int32_t width, int32_t height, float* guides_device) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (!ctx->has_scene) return fail(ctx, RT_ERR_NO_SCENE, "no scene uploaded");
+    if (!ctx->has_camera) return fail(ctx, RT_ERR_NO_CAMERA, "no camera set");
+    if (width < 2 || height < 2 || width > 65536 || height > 65536) return fail(ctx, RT_ERR_INVALID, "width/height must be in [2, 65536]");
+    if (!guides_device) return fail(ctx, RT_ERR_INVALID, "null output");
+    DeviceGuard g(ctx->device);
+    int rc;
+    if ((rc = check_device_range(ctx, guides_device, (size_t)width * height * 2 * sizeof(float4), "rt_render_guides"))) return rc;
+    RT_HIP(ctx, rt::launch_guides(ctx->scene, ctx->camera, width, height, 0.001f, reinterpret_cast<float4*>(guides_device), ctx->stream));
+    return RT_OK;
+}
+
+int rt_reconstruct(rt_context* ctx, const float* rgba_device, const float* guides_device, int32_t width, int32_t height,
+                   const rt_reconstruct_params* p, float* rgba_out_device) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (p && p->struct_size != sizeof(rt_reconstruct_params)) return fail(ctx, RT_ERR_INVALID, "rt_reconstruct_params: struct_size mismatch");
+    if (width < 1 || height < 1 || width > 65536 || height > 65536) return fail(ctx, RT_ERR_INVALID, "width/height must be in [1, 65536]");
+    if (!rgba_device || !guides_device || !rgba_out_device) return fail(ctx, RT_ERR_INVALID, "rt_reconstruct: null buffer");
+    rt::DReconstruct rp{};
+    rp.width = width; rp.height = height;
+    rp.iterations = p && p->iterations ? p->iterations : 4;
+    rp.sigma_color = p ? p->sigma_color : 0.0f;
+    rp.sigma_normal = p && p->sigma_normal != 0.0f ? p->sigma_normal : 16.0f;
+    rp.sigma_depth = p && p->sigma_depth != 0.0f ? p->sigma_depth : 0.05f;
+    rp.albedo_floor = p && p->albedo_floor != 0.0f ? p->albedo_floor : 0.02f;
+    if (rp.iterations < 1 || rp.iterations > 8) return fail(ctx, RT_ERR_INVALID, "rt_reconstruct: iterations must be in [1, 8]");
+    if (!(rp.sigma_color >= 0.0f) || !(rp.sigma_normal > 0.0f) || !(rp.sigma_depth > 0.0f) || !(rp.albedo_floor > 0.0f) ||
+        !std::isfinite(rp.sigma_color) || !std::isfinite(rp.sigma_normal) || !std::isfinite(rp.sigma_depth) || !std::isfinite(rp.albedo_floor))
+        return fail(ctx, RT_ERR_INVALID, "rt_reconstruct: sigmas and albedo_floor must be finite and positive (sigma_color 0 = default)");
+    DeviceGuard g(ctx->device);
+    const size_t n = (size_t)width * height;
+    int rc;
+    if ((rc = check_device_range(ctx, rgba_device, n * sizeof(float4), "rt_reconstruct (frame)")) ||
+        (rc = check_device_range(ctx, guides_device, n * 2 * sizeof(float4), "rt_reconstruct (guides)")) ||
+        (rc = check_device_range(ctx, rgba_out_device, n * sizeof(float4), "rt_reconstruct (result)"))) return rc;
+    if (n > ctx->recon_pixels) {
+        if (ctx->recon_tmp) (void)hipFree(ctx->recon_tmp);          // (waits for the launches that use it)
+        ctx->recon_tmp = nullptr; ctx->recon_pixels = 0;
+        RT_HIP(ctx, hipMalloc((void**)&ctx->recon_tmp, 2 * n * sizeof(float4)));
+        ctx->recon_pixels = n;
+    }
+    RT_HIP(ctx, rt::launch_reconstruct(rp, reinterpret_cast<const float4*>(rgba_device), reinterpret_cast<const float4*>(guides_device),
+                                       ctx->recon_tmp, reinterpret_cast<float4*>(rgba_out_device), ctx->stream));
     return RT_OK;
 }
 

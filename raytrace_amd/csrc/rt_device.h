@@ -150,4 +150,17 @@ hipError_t launch_resolve(const unsigned long long* sums, long long n_pixels, bo
 hipError_t launch_quantize(const float4* rgba, long long n_pixels, int spp, uint8_t* rgb8,
                            hipStream_t stream);
 
+hipError_t launch_guides(const DScene& sc, const DCamera& cam, int width, int height, float t_min, float4* out,
+                         hipStream_t stream);
+
+// rt_reconstruct.hip: the edge-avoiding a-trous passes over a frame and its guides
+struct DReconstruct {
+    int width, height, iterations;
+    float sigma_color;        // <= 0: 1.6 / sqrt(samples of the pixel)
+    float sigma_normal, sigma_depth, albedo_floor;
+};
+// tmp: two float4 images of the frame's size; in, out may be the same buffer
+hipError_t launch_reconstruct(const DReconstruct& rp, const float4* rgba, const float4* guides, float4* tmp, float4* out,
+                              hipStream_t stream);
+
 }  // namespace rt

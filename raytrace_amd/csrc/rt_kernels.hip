@@ -1431,6 +1431,40 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(DScene sc, const float* _
     out[i] = h;
 }
 
+// ---- first-hit guides of the reconstruction stage ------------------------------------------------------------------------------
+
+// Per pixel, the closest hit of the ray through the pixel's centre from the centre of the lens
+// (camera.h:40-45 with a zero lens offset; main.cc:117-118 with the jitter at its mean): plane 0 holds
+// (normal facing against the ray, distance t), plane 1 (albedo of the surface there, list position as
+// int bits; -1 and white where the ray leaves the scene).  What rt_reconstruct weighs its taps by.
+template <int QUANT>
+__global__ __launch_bounds__(kBlock) void guide_kernel(DScene sc, DCamera cam, int width, int height, float inv_wm1, float inv_hm1,
+                                                       float t_min, float4* __restrict__ out) {
+    __shared__ int s_stack[kMaxStack * kBlock];
+    int* stack = s_stack + threadIdx.x;
+    *stack = kTravDone;
+    const long long n = (long long)width * height, i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const int x = (int)(i % width), y = (int)(i / width);
+    const float s = ((float)x + 0.5f) * inv_wm1, t = ((float)y + 0.5f) * inv_hm1;
+    const V3 o = ld3(cam.origin);
+    const V3 d = madd(madd(ld3(cam.llc_rel), s, ld3(cam.horizontal)), t, ld3(cam.vertical));
+    Counters cn = {0, 0, 0, 0, 0, 0, 0, 0};
+    const Cand c = closest_hit<false, QUANT>(sc, o, d, t_min, stack, cn);
+    float4 g0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), g1 = make_float4(1.0f, 1.0f, 1.0f, __int_as_float(-1));
+    if (c.kind >= 0) {
+        const double4 s64 = c.kind == 0 ? sc.sph64[c.idx] : make_double4(0.0, 0.0, 0.0, 1.0);
+        const Rec r = make_record<kFeatAll>(sc, c, o, d, normalise(d, t_min).inv_len, true, true, s64, c.kind == 0 ? sc.sph_info[c.idx].y : 0);
+        const DMaterial m = sc.mats[r.mat];
+        V3 a = mk(1.0f, 1.0f, 1.0f);                                   // a dielectric has no colour (its record holds 1/ir and r0 there)
+        if (m.type != 2) a = material_color(sc, m, r);
+        g0 = make_float4(r.n.x, r.n.y, r.n.z, r.t);
+        g1 = make_float4(fmaxf(a.x, 0.0f), fmaxf(a.y, 0.0f), fmaxf(a.z, 0.0f), __int_as_float(r.obj));
+    }
+    out[i] = g0;
+    out[n + i] = g1;
+}
+
 // ---- write_color (color.h:9-26) ------------------------------------------------------------------------------------------------
 
 // The reference's `scale` is a float and the rest of the expression is double (color.h:17-23);
@@ -1588,6 +1622,18 @@ hipError_t launch_trace(const DScene& sc, const float* rays, int n, float t_min,
         hipLaunchKernelGGL(trace_kernel<1>, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, sc, rays, n, t_min, flags, out);
     else
         hipLaunchKernelGGL(trace_kernel<0>, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, sc, rays, n, t_min, flags, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_guides(const DScene& sc, const DCamera& cam, int width, int height, float t_min, float4* out, hipStream_t stream) {
+    const long long n = (long long)width * height;
+    if (n <= 0) return hipSuccess;
+    const dim3 grid((unsigned)((n + kBlock - 1) / kBlock)), block(kBlock);
+    const float inv_wm1 = (float)(1.0 / (double)(width - 1)), inv_hm1 = (float)(1.0 / (double)(height - 1));
+    if (sc.use_bvh && sc.qnodes != nullptr)
+        hipLaunchKernelGGL(guide_kernel<1>, grid, block, 0, stream, sc, cam, width, height, inv_wm1, inv_hm1, t_min, out);
+    else
+        hipLaunchKernelGGL(guide_kernel<0>, grid, block, 0, stream, sc, cam, width, height, inv_wm1, inv_hm1, t_min, out);
     return hipGetLastError();
 }
 

@@ -1,0 +1,118 @@
+// Low-to-high sample-count reconstruction of a frame (rt_reconstruct of include/rt.h): the edge-avoiding
+// a-trous wavelet transform of Dammertz, Sewtz, Hanika and Lensch (HPG 2010) over the frame's mean
+// radiance, guided by what the ray through each pixel's centre hits first (rt_render_guides: normal,
+// distance, list position, albedo).  The reference names such a stage as ongoing work (README.md:7) and
+// holds no code of it; the frame pairs it is meant for are those of cuda/main.cu:557-576.
+//
+// N passes of a 5x5 B3-spline kernel whose taps stand 2^i pixels apart in pass i.  A tap counts by
+//   h(dx) h(dy) * [same object] * cos(normals)^sigma_normal * exp(-|t_p - t_q| / (sigma_depth t_p))
+//             * exp(-|c_p - c_q|^2 / (sigma_color 2^-i)^2)
+// on the colour demodulated by the first hit's albedo (texture detail is divided out before the
+// passes and multiplied back in after the last one).
+//
+// Bandwidth-bound: per pass and pixel 36 bytes in (colour, normal + distance, object) and 16 out once,
+// and 25 taps through L2.  The blockIdx -> tile map hands each XCD one horizontal band of the image
+// (workgroups go round the eight XCDs, each with its own L2), so the rows a tile's taps reach above and
+// below it are rows its own XCD's other tiles read as well.
+#include "rt_device.h"
+
+namespace rt {
+namespace {
+
+constexpr int kTileW = 32, kTileH = 8, kThreads = kTileW * kTileH;
+
+// mean radiance / albedo; the sample count rides along in w
+__global__ __launch_bounds__(kThreads) void demodulate_kernel(const float4* __restrict__ rgba, const float4* __restrict__ g1,
+                                                              long long n, float albedo_floor, float4* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n) return;
+    const float4 c = rgba[i], a = g1[i];
+    const float inv = 1.0f / fmaxf(c.w, 1.0f);
+    out[i] = make_float4(c.x * inv / fmaxf(a.x, albedo_floor), c.y * inv / fmaxf(a.y, albedo_floor),
+                         c.z * inv / fmaxf(a.z, albedo_floor), c.w);
+}
+
+// One pass.  LAST: the result is multiplied by albedo and sample count again (the convention of rt_render's images).
+template <bool LAST>
+__global__ __launch_bounds__(kThreads) void atrous_kernel(const float4* __restrict__ cin, const float4* __restrict__ g0,
+                                                          const float4* __restrict__ g1, int width, int height, int step,
+                                                          float sigma_color, float pass_scale /* 4^pass */, float sigma_normal,
+                                                          float inv_sigma_depth, float albedo_floor, int band_rows, int tiles_x,
+                                                          float4* __restrict__ cout) {
+    // workgroup b runs on XCD b % 8: that XCD's band of tile rows, tiles in row-major order within it
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int ty = xcd * band_rows + slot / tiles_x, tx = slot % tiles_x;
+    if (slot / tiles_x >= band_rows) return;
+    const int x = tx * kTileW + (threadIdx.x % kTileW), y = ty * kTileH + (threadIdx.x / kTileW);
+    if (x >= width || y >= height) return;
+    const long long at = (long long)y * width + x;
+    const float4 cp = cin[at], gp = g0[at];
+    const int idp = __float_as_int(g1[at].w);
+    const bool hit = idp >= 0;
+    const float sc = sigma_color > 0.0f ? sigma_color : 1.6f * __builtin_amdgcn_rsqf(fmaxf(cp.w, 1.0f));
+    const float k_color = -1.4426950408889634f * pass_scale / (sc * sc);          // exponents are taken to base 2
+    const float k_depth = hit ? -1.4426950408889634f * inv_sigma_depth / fmaxf(gp.w, 1.0e-6f) : 0.0f;
+    const float k_normal = hit ? sigma_normal : 0.0f;
+    const float b3[5] = {0.0625f, 0.25f, 0.375f, 0.25f, 0.0625f};
+    float ax = 0.0f, ay = 0.0f, az = 0.0f, wsum = 0.0f;
+#pragma unroll
+    for (int dy = -2; dy <= 2; dy++) {
+        const int qy = y + dy * step;
+        if (qy < 0 || qy >= height) continue;
+#pragma unroll
+        for (int dx = -2; dx <= 2; dx++) {
+            const int qx = x + dx * step;
+            if (qx < 0 || qx >= width) continue;
+            const long long q = (long long)qy * width + qx;
+            const int idq = __float_as_int(g1[q].w);
+            if (idq != idp) continue;
+            const float4 cq = cin[q], gq = g0[q];
+            const float cosn = fminf(fmaxf(fmaf(gp.z, gq.z, fmaf(gp.y, gq.y, gp.x * gq.x)), 1.0e-6f), 1.0f);
+            const float ex = cq.x - cp.x, ey = cq.y - cp.y, ez = cq.z - cp.z;
+            const float d2 = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
+            const float e = fmaf(k_normal, __builtin_amdgcn_logf(cosn), fmaf(k_depth, fabsf(gp.w - gq.w), k_color * d2));
+            const float w = b3[dy + 2] * b3[dx + 2] * __builtin_amdgcn_exp2f(e);
+            ax = fmaf(w, cq.x, ax); ay = fmaf(w, cq.y, ay); az = fmaf(w, cq.z, az);
+            wsum += w;
+        }
+    }
+    const float inv = 1.0f / wsum;                   // the centre tap always counts: wsum >= 9/64
+    float4 r = make_float4(ax * inv, ay * inv, az * inv, cp.w);
+    if (LAST) {
+        const float4 a = g1[at];
+        r.x *= fmaxf(a.x, albedo_floor) * cp.w; r.y *= fmaxf(a.y, albedo_floor) * cp.w; r.z *= fmaxf(a.z, albedo_floor) * cp.w;
+    }
+    cout[at] = r;
+}
+
+}  // namespace
+
+hipError_t launch_reconstruct(const DReconstruct& rp, const float4* rgba, const float4* guides, float4* tmp, float4* out,
+                              hipStream_t stream) {
+    const long long n = (long long)rp.width * rp.height;
+    if (n <= 0) return hipSuccess;
+    const float4* g0 = guides;
+    const float4* g1 = guides + n;
+    float4* a = tmp;
+    float4* b = tmp + n;
+    hipLaunchKernelGGL(demodulate_kernel, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, stream, rgba, g1, n,
+                       rp.albedo_floor, a);
+    const int tiles_x = (rp.width + kTileW - 1) / kTileW, tiles_y = (rp.height + kTileH - 1) / kTileH;
+    const int band_rows = (tiles_y + 7) / 8;
+    const dim3 grid((unsigned)(8 * band_rows * tiles_x)), block(kThreads);
+    float scale = 1.0f;
+    for (int it = 0; it < rp.iterations; it++, scale *= 4.0f) {
+        const bool last = it == rp.iterations - 1;
+        float4* dst = last ? out : b;
+        if (last)
+            hipLaunchKernelGGL(atrous_kernel<true>, grid, block, 0, stream, a, g0, g1, rp.width, rp.height, 1 << it, rp.sigma_color, scale,
+                               rp.sigma_normal, 1.0f / rp.sigma_depth, rp.albedo_floor, band_rows, tiles_x, dst);
+        else
+            hipLaunchKernelGGL(atrous_kernel<false>, grid, block, 0, stream, a, g0, g1, rp.width, rp.height, 1 << it, rp.sigma_color, scale,
+                               rp.sigma_normal, 1.0f / rp.sigma_depth, rp.albedo_floor, band_rows, tiles_x, dst);
+        float4* t = a; a = b; b = t;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace rt

@@ -107,14 +107,20 @@ def render_sequence(ctx, cam: S.camera, frames, width: int, height: int, spp: in
 
 
 def render_pairs(ctx, cam: S.camera, frames, width: int, height: int, low_spp: int, high_spp: int, out_dir: str | None,
-                 max_depth: int = 25, seed: int = 1, fmt: str = "p3", rank: int = 0, world: int = 1, first_frame: int = 0):
+                 max_depth: int = 25, seed: int = 1, fmt: str = "p3", rank: int = 0, world: int = 1, first_frame: int = 0,
+                 reconstruct: bool = False):
     """The reference's "low-high samples of each image" loop (cuda/main.cu:557-583: image_<frame>_low at
     low_num_samples, image_<frame>_high at high_num_samples, main.cu:445-446, :569, :575) for the cost of
     the high frames alone.  Samples are keyed by their index, so the low frame is the first low_spp
     samples of the high one: each frame is rendered as two windows of samples into integer sums, the low
     file is written from the first window and the high file from the two windows added (integer sums
     add exactly: the high file is bit for bit the one a single render at high_spp writes).
-    Returns [(frame, rays, kernel_ms)] with both windows counted."""
+    Returns [(frame, rays, kernel_ms)] with both windows counted.
+
+    reconstruct: also turn every low frame into an estimate of its high frame (rt_render_guides +
+    rt_reconstruct: the stage the reference's README.md:7 names as ongoing work and these pairs are laid
+    out for), write it as image_<frame>_recon, and return [(frame, rays, kernel_ms, psnr_low, psnr_recon)]:
+    the peak signal-to-noise ratio of the displayed low and reconstructed frames against the high one."""
     import torch
 
     from . import api
@@ -127,11 +133,19 @@ def render_pairs(ctx, cam: S.camera, frames, width: int, height: int, low_spp: i
     sums = [torch.zeros((height, width, 4), dtype=torch.int64, device=dev) for _ in range(2)]   # 32.32 sums as their bit patterns
     fb = torch.zeros((height, width, 4), dtype=torch.float32, device=dev)
     rgb = torch.zeros((height, width, 3), dtype=torch.uint8, device=dev)
+    guides = torch.zeros((2, height, width, 4), dtype=torch.float32, device=dev) if reconstruct else None
+    shown = {}
     torch.cuda.synchronize()
     done = []
 
     def write(frame, quality, spp, sums_t):
         ctx.resolve_sums(sums_t.data_ptr(), width * height, fb.data_ptr())
+        if quality == "recon":
+            ctx.render_guides(width, height, guides.data_ptr())
+            ctx.reconstruct(fb.data_ptr(), guides.data_ptr(), width, height, fb.data_ptr())
+        if reconstruct:                                         # the displayed frame: color.h:17-23 without the bytes
+            ctx.stats()
+            shown[quality] = torch.sqrt(torch.clamp(fb[..., :3] / spp, 0.0, 1.0))
         ctx.quantize(fb.data_ptr(), width * height, spp, rgb.data_ptr())
         ctx.stats()                                             # waits for the context's stream
         img = rgb.cpu().numpy()
@@ -158,10 +172,16 @@ def render_pairs(ctx, cam: S.camera, frames, width: int, height: int, low_spp: i
             st = ctx.stats()
             rays, ms = rays + st["rays"], ms + st["kernel_ms"]
         write(frame, "low", low_spp, sums[0])
+        if reconstruct:
+            write(frame, "recon", low_spp, sums[0])
         sums[1] += sums[0]                                      # (on torch's stream; the context's is idle: write() waited)
         torch.cuda.synchronize()
         write(frame, "high", high_spp, sums[1])
-        done.append((frame, rays, ms))
+        if reconstruct:
+            psnr = {q: float(-10.0 * torch.log10(torch.mean((shown[q] - shown["high"]) ** 2))) for q in ("low", "recon")}
+            done.append((frame, rays, ms, psnr["low"], psnr["recon"]))
+        else:
+            done.append((frame, rays, ms))
     return done
 
 

@@ -149,13 +149,20 @@ def test_a_device_buffer_that_is_too_small_is_an_error_not_a_fault(api, rtiow_fl
                 lambda: c.render(api.Context.params(W, H, 2, 50, 1, flags=api.RT_FLAG_FIXED_SUMS), full.value),
                 lambda: c.quantize(short.value, W * H, 2, rgb.value),
                 lambda: c.quantize(full.value, W * H + 1, 2, rgb.value),
-                lambda: c.resolve_sums(sums.value, W * H, short.value)):
+                lambda: c.resolve_sums(sums.value, W * H, short.value),
+                lambda: c.render_guides(W, H, sums.value + 16),                 # two planes of float4: exactly the 32 bytes a pixel of `sums`
+                lambda: c.reconstruct(short.value, sums.value, W, H, full.value),
+                lambda: c.reconstruct(full.value, short.value, W, H, full.value),
+                lambda: c.reconstruct(full.value, sums.value, W, H, short.value)):
         with pytest.raises(api.RtError) as e:
             bad()
         assert e.value.code == api.RT_ERR_INVALID and "bytes" in str(e.value)
     c.render(api.Context.params(W, H, 2, 50, 1, flags=api.RT_FLAG_FIXED_SUMS), sums.value)
     c.resolve_sums(sums.value, W * H, full.value)
     c.quantize(full.value, W * H, 2, rgb.value)
+    c.render(p, full.value)
+    c.render_guides(W, H, sums.value)
+    c.reconstruct(full.value, sums.value, W, H, full.value)
     c.stats()                                                                   # waits for the stream: nothing faulted
     c.close()
     for b in (full, short, sums, rgb):

@@ -92,4 +92,15 @@ def test_low_high_pairs_are_the_files_of_two_sequences(tmp_path):
         open(sequence.frame_path(str(tmp_path / "pairs"), 1, "p3", "high")).read()
     with pytest.raises(ValueError):
         sequence.render_pairs(ctx, S.rtiow_camera(W / H), 1, W, H, 4, 4, None)
+    # with the reconstruction stage: the same low and high files, a third file per frame between them in quality
+    rec = sequence.render_pairs(ctx, S.rtiow_camera(W / H), 2, 192, 108, 2, 128, str(tmp_path / "rec"), first_frame=1, fmt="p6", reconstruct=True)
+    plain = sequence.render_pairs(ctx, S.rtiow_camera(W / H), 2, 192, 108, 2, 128, str(tmp_path / "plain"), first_frame=1, fmt="p6")
+    for (f, rays, _, psnr_low, psnr_recon), (f2, rays2, _) in zip(rec, plain):
+        assert (f, rays) == (f2, rays2)
+        assert psnr_recon > psnr_low + 4.0, (psnr_low, psnr_recon)
+        for quality in ("low", "high"):
+            assert open(sequence.frame_path(str(tmp_path / "rec"), f, "p6", quality), "rb").read() == \
+                open(sequence.frame_path(str(tmp_path / "plain"), f, "p6", quality), "rb").read()
+        assert os.path.getsize(sequence.frame_path(str(tmp_path / "rec"), f, "p6", "recon")) == \
+            os.path.getsize(sequence.frame_path(str(tmp_path / "rec"), f, "p6", "low"))
     ctx.close()

@@ -8,5 +8,5 @@ name=$1; shift
 mkdir -p ../../build_variants
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -shared --offload-arch=gfx950 -fno-gpu-rdc -Wall -Wno-unused-function \
     -ffp-contract=on -fno-slp-vectorize "$@" \
-    -x hip rt_api.cpp -x hip rt_bvh.cpp -x c++ rt_image.cpp -x hip rt_kernels.hip -x hip rt_lbvh.hip -o ../../build_variants/librt_$name.so
+    -x hip rt_api.cpp -x hip rt_bvh.cpp -x c++ rt_image.cpp -x hip rt_kernels.hip -x hip rt_lbvh.hip -x hip rt_reconstruct.hip -o ../../build_variants/librt_$name.so
 echo built build_variants/librt_$name.so
