@@ -429,10 +429,27 @@ __device__ __forceinline__ RayN normalise(V3 d, float t_min) {
 //                   its throughput times the background where it leaves the scene, and the running sum
 //                   of emitted light (three registers for the whole path) is not kept
 constexpr int kFeatRects = 1, kFeatTextures = 2, kFeatInstances = 4, kFeatEmitters = 8, kFeatAll = 15;
+// A room's rects (at most kLdsRects of them: kFeatRoom, kFeatTexturedRoom) are read from a copy in LDS, every
+// lane the same record at a time (a broadcast): as scalar-load operands they make every instruction of the
+// rect test issue at half rate, and a loop over six of them cannot hide six scalar-load latencies.
+constexpr int kLdsRects = 16;
+typedef const DRect __attribute__((address_space(3))) lds_crect;
+__host__ __device__ constexpr bool staged_rects(int feat) { return (feat & kFeatRects) != 0 && feat != kFeatAll; }
+template <int FEAT>
+__device__ __forceinline__ DRect rect_record(const DScene& sc, lds_crect* staged, int i) {
+    if constexpr (staged_rects(FEAT)) {
+        lds_crect& s = staged[i];
+        DRect r;
+        r.a0 = s.a0; r.a1 = s.a1; r.b0 = s.b0; r.b1 = s.b1; r.k = s.k; r.axes = s.axes; r.obj = s.obj; r.mat = s.mat;
+        return r;
+    } else {
+        return sc.rects[i];
+    }
+}
 constexpr int kFeatRoom = kFeatRects | kFeatEmitters;   // the combinations kernels are built for besides none and all:
 constexpr int kFeatTexturedRoom = kFeatRoom | kFeatTextures;   // a room with its light, the same with textures, kFeatTextures alone
 template <bool COUNT, int FEAT>
-__device__ __forceinline__ void hit_always(const DScene& sc, V3 o, V3 d, const RayN& rn, float t_min, Origin from,
+__device__ __forceinline__ void hit_always(const DScene& sc, lds_crect* staged, V3 o, V3 d, const RayN& rn, float t_min, Origin from,
                                            Cand& best, Counters& cn) {
     const int from_wide = from.wide(), from_rect = from.rect();
     for (int i = 0; i < sc.n_wide; i++) {
@@ -450,7 +467,7 @@ __device__ __forceinline__ void hit_always(const DScene& sc, V3 o, V3 d, const R
         if (sc.n_rects > 0) inv_d = mk(polished_rcp(d.x), polished_rcp(d.y), polished_rcp(d.z));
     if constexpr (RECTS)
     for (int i = 0; i < sc.n_rects; i++) {
-        const DRect r = sc.rects[i];
+        const DRect r = rect_record<FEAT>(sc, staged, i);
         float t;
         if (COUNT) cn.rect++;
         if (i == from_rect) continue;
@@ -759,7 +776,7 @@ __device__ __forceinline__ void face(Rec& r, V3 d, V3 outward) {
 // a float division), then p and the normal from the polished t.
 // `s64` is the winning ordinary sphere in double and `mat` its material, both loaded by the caller.
 template <int FEAT>
-__device__ __forceinline__ Rec make_record(const DScene& sc, const Cand& c, V3 o, V3 d, float inv_len, bool refine, bool want_uv,
+__device__ __forceinline__ Rec make_record(const DScene& sc, lds_crect* staged, const Cand& c, V3 o, V3 d, float inv_len, bool refine, bool want_uv,
                                            double4 s64, int mat) {
     constexpr bool RECTS = (FEAT & kFeatRects) != 0, TEX = (FEAT & kFeatTextures) != 0, INST = (FEAT & kFeatInstances) != 0;
     if constexpr (!TEX) want_uv = false;
@@ -768,7 +785,7 @@ __device__ __forceinline__ Rec make_record(const DScene& sc, const Cand& c, V3 o
     r.u = 0.0f; r.v = 0.0f;
     r.hollow = false;
     if (RECTS && c.kind == 2) {
-        const DRect q = sc.rects[c.idx];
+        const DRect q = rect_record<FEAT>(sc, staged, c.idx);
         int ka = q.axes & 3, aa = (q.axes >> 2) & 3, ba = (q.axes >> 4) & 3;
         float t = c.tn * inv_len;
         r.t = t;
@@ -1065,7 +1082,7 @@ __device__ __forceinline__ unsigned long long clk() { return __builtin_amdgcn_s_
 // Shade one finished closest-hit query: returns true when the path ended (sample complete).
 // L collects the path's radiance: emitted light along the way and the background at the end.
 template <bool COUNT, int FEAT, class G>
-__device__ __forceinline__ bool shade(const DScene& sc, const G& geo, const DRender& rp, const Cand& c, const Key& key, int depth,
+__device__ __forceinline__ bool shade(const DScene& sc, lds_crect* staged, const G& geo, const DRender& rp, const Cand& c, const Key& key, int depth,
                                       bool refine, const RayN& rn, V3& o, V3& d, V3& T, V3& L, Origin& from, Counters& cn) {
     constexpr bool RECTS = (FEAT & kFeatRects) != 0, TEX = (FEAT & kFeatTextures) != 0, EMIT = (FEAT & kFeatEmitters) != 0;
     // without emitters nothing is added along the way: L is written where a path ends, and only there
@@ -1076,7 +1093,7 @@ __device__ __forceinline__ bool shade(const DScene& sc, const G& geo, const DRen
     }
     // the loads the record and the material need go out first; the Philox block below is pure
     // arithmetic and runs while they are in flight
-    const int mat = c.kind == 0 ? geo.mat(c.idx) : ((!RECTS || c.kind == 1) ? sc.wide[c.idx].mat : sc.rects[c.idx].mat);
+    const int mat = c.kind == 0 ? geo.mat(c.idx) : ((!RECTS || c.kind == 1) ? sc.wide[c.idx].mat : (staged_rects(FEAT) ? staged[c.idx].mat : sc.rects[c.idx].mat));
     const double4 s64 = c.kind == 0 ? sc.sph64[c.idx] : make_double4(0.0, 0.0, 0.0, 1.0);
     DMaterial m = sc.mats[mat];
     if (!TEX) m.tex = -1;          // a kernel for scenes without textures keeps none of that code
@@ -1085,7 +1102,7 @@ __device__ __forceinline__ bool shade(const DScene& sc, const G& geo, const DRen
     // code: the walk out of HBM with that code is the one kernel it costs registers it does not have;
     // the kernels that read their geometry from HBM want their loads kept behind the block: rt_philox.h)
     const uint4 w = philox4x32_10<FEAT == 0 || G::kPlaneAddressed, !G::kPlaneAddressed>(key.pixel, key.sample, (uint32_t)depth, 0u, key.seed_lo, key.seed_hi);
-    Rec r = make_record<FEAT>(sc, c, o, d, rn.inv_len, refine, m.tex >= 0, s64, mat);
+    Rec r = make_record<FEAT>(sc, staged, c, o, d, rn.inv_len, refine, m.tex >= 0, s64, mat);
     V3 att, sd, em;
     if (COUNT) cn.shade++;
     V3 rs = mk(0.0f, 0.0f, 0.0f);
@@ -1197,6 +1214,13 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? RT_WG_PER_CU_SCAN : (LDS ? (MOD
     // half rate.
     __shared__ DCamera s_cam;
     if (threadIdx.x < sizeof(DCamera) / sizeof(float)) reinterpret_cast<float*>(&s_cam)[threadIdx.x] = reinterpret_cast<const float*>(&cam)[threadIdx.x];
+    // a room's rects (the launch picks these kernels for at most kLdsRects of them)
+    __shared__ __align__(16) DRect s_rects[staged_rects(FEAT) ? kLdsRects : 1];
+    lds_crect* staged = (lds_crect*)(size_t)(__attribute__((address_space(3))) char*)s_rects;
+    if constexpr (staged_rects(FEAT)) {
+        static_assert(sizeof(DRect) == 32, "a rect record is eight words");
+        if (threadIdx.x < 8 * sc.n_rects) reinterpret_cast<int*>(s_rects)[threadIdx.x] = reinterpret_cast<const int*>(sc.rects)[threadIdx.x];
+    }
     // the entry below every walk's stack (see hit_bvh)
     if constexpr (BVH) {
         if constexpr (LDS) *reinterpret_cast<short*>(stack) = (short)kDone; else *stack = kDone;
@@ -1346,7 +1370,7 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? RT_WG_PER_CU_SCAN : (LDS ? (MOD
             int& spq = *(SLICED ? &sp : &sp_trip);
             if (curq == kDone) {                       // a new ray: always-tested primitives first
                 cq = no_hit();
-                hit_always<COUNT, FEAT>(sc, o, d, rn, rp.t_min, from, cq, cn);
+                hit_always<COUNT, FEAT>(sc, staged, o, d, rn, rp.t_min, from, cq, cn);
                 nrays++;
                 depth++;
                 if constexpr (!BVH) hit_list<COUNT, LDS>(sc, staged_list, o, rn, from, cq, cn);
@@ -1357,7 +1381,7 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? RT_WG_PER_CU_SCAN : (LDS ? (MOD
                 if (curq != kDone) hit_bvh<COUNT, MODE == 2 ? 1 : (MODE == 3 ? 2 : 0)>(geo, o, rn, from, stack, rp.stack_entries, rp.slice, rp.leaf_quorum, curq, spq, cq, cn);
             if (PROF) { unsigned long long t = clk(); ph[2] += t - tq; tq = t; }
             if (curq == kDone) {                       // query finished (else: resumed next trip)
-                if (shade<COUNT, FEAT>(sc, geo, rp, cq, key, depth, refine, rn, o, d, T, L, from, cn)) {
+                if (shade<COUNT, FEAT>(sc, staged, geo, rp, cq, key, depth, refine, rn, o, d, T, L, from, cn)) {
                     atomicAdd(&accum[q * 3 + 0], to_fixed(L.x));
                     atomicAdd(&accum[q * 3 + 1], to_fixed(L.y));
                     atomicAdd(&accum[q * 3 + 2], to_fixed(L.z));
@@ -1394,7 +1418,7 @@ template <bool COUNT, int QUANT>
 __device__ __forceinline__ Cand closest_hit(const DScene& sc, V3 o, V3 d, float t_min, int* stack, Counters& cn) {
     Cand best = no_hit();
     RayN rn = normalise(d, t_min);
-    hit_always<COUNT, kFeatAll>(sc, o, d, rn, t_min, no_origin(), best, cn);
+    hit_always<COUNT, kFeatAll>(sc, nullptr, o, d, rn, t_min, no_origin(), best, cn);
     const auto geo = stage_geometry<false, QUANT>(sc, nullptr);
     if (!sc.use_bvh) hit_list<COUNT, false>(sc, nullptr, o, rn, no_origin(), best, cn);
     else if (sc.root != kNoBvh) {
@@ -1423,7 +1447,7 @@ __global__ __launch_bounds__(kBlock) void trace_kernel(DScene sc, const float* _
         for (int a = 0; a < 3; a++) { h.p[a] = 0.0f; h.n[a] = 0.0f; }
     } else {
         const double4 s64 = c.kind == 0 ? sc.sph64[c.idx] : make_double4(0.0, 0.0, 0.0, 1.0);
-        Rec r = make_record<kFeatAll>(sc, c, o, d, normalise(d, t_min).inv_len, (flags & 2u) == 0u, true, s64, c.kind == 0 ? sc.sph_info[c.idx].y : 0);
+        Rec r = make_record<kFeatAll>(sc, nullptr, c, o, d, normalise(d, t_min).inv_len, (flags & 2u) == 0u, true, s64, c.kind == 0 ? sc.sph_info[c.idx].y : 0);
         h.id = r.obj; h.t = r.t; h.front = r.front; h.u = r.u; h.v = r.v;
         h.p[0] = r.p.x; h.p[1] = r.p.y; h.p[2] = r.p.z;
         h.n[0] = r.n.x; h.n[1] = r.n.y; h.n[2] = r.n.z;
@@ -1454,7 +1478,7 @@ __global__ __launch_bounds__(kBlock) void guide_kernel(DScene sc, DCamera cam, i
     float4 g0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), g1 = make_float4(1.0f, 1.0f, 1.0f, __int_as_float(-1));
     if (c.kind >= 0) {
         const double4 s64 = c.kind == 0 ? sc.sph64[c.idx] : make_double4(0.0, 0.0, 0.0, 1.0);
-        const Rec r = make_record<kFeatAll>(sc, c, o, d, normalise(d, t_min).inv_len, true, true, s64, c.kind == 0 ? sc.sph_info[c.idx].y : 0);
+        const Rec r = make_record<kFeatAll>(sc, nullptr, c, o, d, normalise(d, t_min).inv_len, true, true, s64, c.kind == 0 ? sc.sph_info[c.idx].y : 0);
         const DMaterial m = sc.mats[r.mat];
         V3 a = mk(1.0f, 1.0f, 1.0f);                                   // a dielectric has no colour (its record holds 1/ir and r0 there)
         if (m.type != 2) a = material_color(sc, m, r);
@@ -1594,6 +1618,7 @@ hipError_t launch_render(const DScene& sc, const DCamera& cam, const DRender& rp
                ((sc.has_textures & 4) ? kFeatEmitters : 0);
     if ((feat & kFeatInstances) || ((count || prof) && feat != 0) || (rp.flags & 256u) != 0u) feat = kFeatAll;
     else if (feat != 0 && feat != kFeatTextures) feat = (feat & kFeatTextures) ? kFeatTexturedRoom : kFeatRoom;   // the built combination that covers it
+    if (staged_rects(feat) && sc.n_rects > kLdsRects) feat = kFeatAll;       // more rects than a room's: read through scalar loads
 #define RT_LAUNCH_Q(C, L, P, M, F) do { if (!L && M == 2 && quant && deep) RT_LAUNCH(C, L, P, M, F, ((!L && M == 2) ? 2 : 0)); \
         else if (!L && M != 0 && quant) RT_LAUNCH(C, L, P, M, F, ((!L && M != 0) ? 1 : 0)); else RT_LAUNCH(C, L, P, M, F, 0); } while (0)
 #define RT_LAUNCH_F(C, L, P, M) do { if (feat == 0) RT_LAUNCH_Q(C, L, P, M, 0); else if (feat == kFeatAll) RT_LAUNCH_Q(C, L, P, M, kFeatAll); \

@@ -11,11 +11,11 @@ EXTRA="$*"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- \
-    python3 "$ROOT/bench.py" --config $CFG --steps 10 --warmup 2 --frames-in-flight 1 $EXTRA > "$OUT/bench_traced.json" 2> "$OUT/bench_traced.err" || exit 1
+    python3 "$ROOT/bench.py" --config $CFG --steps 10 --warmup 2 --frames-in-flight 1 --no-other-configs $EXTRA > "$OUT/bench_traced.json" 2> "$OUT/bench_traced.err" || exit 1
 pass() {   # name, counters...
     local name=$1; shift
     timeout -s KILL 200 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/pmc_$name" -- \
-        python3 "$ROOT/bench.py" --config $CFG --steps 2 --warmup 0 --frames-in-flight 1 --no-cpu-baseline $EXTRA > "$OUT/pmc_$name.log" 2>&1 || exit 1
+        python3 "$ROOT/bench.py" --config $CFG --steps 2 --warmup 0 --frames-in-flight 1 --no-cpu-baseline --no-other-configs $EXTRA > "$OUT/pmc_$name.log" 2>&1 || exit 1
 }
 pass fetch FETCH_SIZE
 pass write WRITE_SIZE

@@ -75,9 +75,12 @@ if main:
         "fetch_correction": "x2 (gfx950 FETCH_SIZE tallies 128-B requests at 64 B; calibrated for wide streaming reads, "
                             "taken as an upper bound for the 16-B-per-lane node and sphere fetches of the tree walk)",
         "hbm_bytes_per_launch": int(fetch_kb * 1024 * 2 + write_kb * 1024),
-        "algorithmic_bytes_per_launch": W * H * 16,
+        # framebuffer, plus one 32-byte node per node visit where the tree is walked out of HBM (counting launch of the traced run)
+        "algorithmic_bytes_per_launch": ((bench or {}).get("roofline", {}).get("memory_side") or {}).get("algorithmic_bytes_per_launch", W * H * 16),
+        "framebuffer_bytes": W * H * 16,
         "note": "framebuffer float4 stores in 64-B row segments of the 4x2 wave tile; scenes that fit are read once per "
-                "workgroup into LDS, larger ones (c4) are walked through L1/L2 and their misses are the fetches",
+                "workgroup into LDS, larger ones (c4) are walked through L1/L2 and their misses are the fetches "
+                "(algorithmic bytes then count one 32-byte node per node visit, nearly all of them served by the caches)",
     }
     with open(os.path.join(dst, "hbm_traffic.json" if cfg == "c2" else f"{cfg}_hbm_traffic.json"), "w") as f:
         json.dump(traffic, f, indent=1)
