@@ -27,7 +27,7 @@ def p3_bytes(rgb8_bottom_up: np.ndarray) -> bytes:
 
 
 def write_p3(path: str, rgb8_bottom_up: np.ndarray) -> None:
-    """The file p3_bytes describes, written by the library (rt_write_ppm: 8 ms for a 1080p frame)."""
+    """The file p3_bytes describes, written by the library (rt_write_ppm: 5 ms of host time for a 1080p frame)."""
     from . import api
     api.write_ppm(path, rgb8_bottom_up, binary=False)
 
