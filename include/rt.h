@@ -19,7 +19,7 @@
  *   write_color / output_image   color.h:9-26,
  *                                cuda/main.cu:358-383      rt_quantize
  *   low / high frame pairs       cuda/main.cu:557-576,
- *                                README.md:7               rt_render_guides + rt_reconstruct (no code in the reference)
+ *                                README.md:7               rt_render_guides + rt_reconstruct + rt_upscale (no code in the reference)
  *   gpuErrchk                    cuda/main.cu:24-32        return codes + rt_last_error
  *
  * Conventions: every function returns RT_OK (0) or a negative rt_error; nothing exits or
@@ -275,6 +275,19 @@ typedef struct rt_reconstruct_params {
     float albedo_floor;          /* 0 = default (0.02) */
 } rt_reconstruct_params;
 int rt_render_guides(rt_context* ctx, int32_t width, int32_t height, float* guides_device);
+/* rt_upscale: a frame rendered at a low resolution onto a higher-resolution pixel grid (the "upscaler" half of
+ *   README.md:7), by joint bilateral upsampling (Kopf, Cohen, Lischinski, Uyttendaele, SIGGRAPH 2007): a
+ *   high-resolution pixel takes the 3x3 low-resolution pixels around its own position in the image, each counted
+ *   by a tent in image distance and by how well the first hit of its centre ray (guides_low_device:
+ *   rt_render_guides at the low size) agrees with the high-resolution pixel's (guides_high_device:
+ *   rt_render_guides at the high size; same camera) in object, normal and distance; colours are divided by the
+ *   low-resolution albedo and multiplied by the high-resolution one, so texture detail and silhouettes are those
+ *   of the high-resolution guides.  Any ratio of sizes up to 4 per axis; typically the low frame has been through
+ *   rt_reconstruct first.  iterations and sigma_color of params are not used.  Same image convention as
+ *   rt_reconstruct (the sample count of the nearest low-resolution pixel rides along).  Asynchronous. */
+int rt_upscale(rt_context* ctx, const float* rgba_low_device, const float* guides_low_device, int32_t low_width, int32_t low_height,
+               const float* guides_high_device, int32_t width, int32_t height, const rt_reconstruct_params* params,
+               float* rgba_out_device);
 int rt_reconstruct(rt_context* ctx, const float* rgba_device, const float* guides_device, int32_t width, int32_t height,
                    const rt_reconstruct_params* params, float* rgba_out_device);
 

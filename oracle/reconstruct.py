@@ -85,6 +85,53 @@ def reconstruct(rgba, g0, g1, ids, iterations=4, sigma_color=0.0, sigma_normal=1
     return out
 
 
+def upscale(rgba_low, g0l, g1l, idl, g0h, g1h, idh, sigma_normal=16.0, sigma_depth=0.05, albedo_floor=0.02):
+    """Joint bilateral upsampling (Kopf et al. 2007) of a low-resolution frame onto the grid of the high-resolution
+    guides, as rt_upscale does it: 3x3 low-resolution taps around the pixel's own position, tent weights of width 1.5
+    low pixels times guide agreement, on demodulated colours; remodulated by the high-resolution albedo; tent weights
+    alone where no tap agrees.  Returns [H, W, 4]."""
+    lh, lw = idl.shape
+    hh, hw = idh.shape
+    spp_l = rgba_low[..., 3].astype(np.float64)
+    c = rgba_low[..., :3].astype(np.float64) / np.maximum(spp_l, 1.0)[..., None] / np.maximum(g1l.astype(np.float64), albedo_floor)
+    f32 = np.float32
+    ux = ((np.arange(hw, dtype=f32) + f32(0.5)) * (f32(lw - 1) / f32(hw - 1)) - f32(0.5)).astype(np.float64)
+    uy = ((np.arange(hh, dtype=f32) + f32(0.5)) * (f32(lh - 1) / f32(hh - 1)) - f32(0.5)).astype(np.float64)
+    bx, by = np.floor(ux + 0.5).astype(int), np.floor(uy + 0.5).astype(int)
+    nrm, dist, hit = g0h[..., :3].astype(np.float64), g0h[..., 3].astype(np.float64), idh >= 0
+    acc, wsum, bacc, bsum = np.zeros((hh, hw, 3)), np.zeros((hh, hw)), np.zeros((hh, hw, 3)), np.zeros((hh, hw))
+    for dy in (-1, 0, 1):
+        for dx in (-1, 0, 1):
+            qx, qy = np.clip(bx + dx, 0, lw - 1), np.clip(by + dy, 0, lh - 1)
+            tent = np.maximum(1.0 - np.abs(by + dy - uy) / 1.5, 0.0)[:, None] * np.maximum(1.0 - np.abs(bx + dx - ux) / 1.5, 0.0)[None, :]
+            qc, qn, qd, qid = c[qy][:, qx], g0l[qy][:, qx][..., :3].astype(np.float64), g0l[qy][:, qx][..., 3].astype(np.float64), idl[qy][:, qx]
+            bacc += tent[..., None] * qc
+            bsum += tent
+            cosn = np.clip(np.sum(nrm * qn, axis=2), 1e-6, 1.0)
+            geo = np.exp2(sigma_normal * np.log2(cosn)) * np.exp(-np.abs(dist - qd) / (sigma_depth * np.maximum(dist, 1e-6)))
+            w = np.where(qid == idh, tent, 0.0) * np.where(hit, geo, 1.0)
+            acc += w[..., None] * qc
+            wsum += w
+    agreed = wsum > 1e-4
+    res = np.where(agreed[..., None], acc / np.where(agreed, wsum, 1.0)[..., None], bacc / bsum[..., None])
+    spp = spp_l[np.clip(by, 0, lh - 1)][:, np.clip(bx, 0, lw - 1)]
+    return np.concatenate([res * np.maximum(g1h.astype(np.float64), albedo_floor) * spp[..., None], spp[..., None]], axis=2)
+
+
+def bilinear(rgba_low, hw, hh):
+    """Plain tent-weighted upsampling of the mean radiance with the same pixel mapping (the baseline rt_upscale is held against)."""
+    lh, lw = rgba_low.shape[:2]
+    m = rgba_low[..., :3].astype(np.float64) / np.maximum(rgba_low[..., 3:4], 1.0)
+    ux = (np.arange(hw) + 0.5) * ((lw - 1) / (hw - 1)) - 0.5
+    uy = (np.arange(hh) + 0.5) * ((lh - 1) / (hh - 1)) - 0.5
+    x0, y0 = np.clip(np.floor(ux).astype(int), 0, lw - 2), np.clip(np.floor(uy).astype(int), 0, lh - 2)
+    fx, fy = np.clip(ux - x0, 0, 1)[None, :, None], np.clip(uy - y0, 0, 1)[:, None, None]
+    a, b, c2, d = m[y0][:, x0], m[y0][:, x0 + 1], m[y0 + 1][:, x0], m[y0 + 1][:, x0 + 1]
+    out = (a * (1 - fx) + b * fx) * (1 - fy) + (c2 * (1 - fx) + d * fx) * fy
+    spp = float(rgba_low[0, 0, 3])
+    return np.concatenate([out * spp, np.full((hh, hw, 1), spp)], axis=2)
+
+
 def psnr(img, ref, spp_img, spp_ref):
     """Peak signal-to-noise ratio of the displayed images: mean radiance through the reference's gamma 2 and
     clamp (color.h:17-23), peak 1."""

@@ -20,7 +20,7 @@ RT_FLAG_ALL_FEATURES = 256
 
 EXPORTS = ["rt_create", "rt_destroy", "rt_set_stream", "rt_upload_scene", "rt_set_camera",
            "rt_shard_rows", "rt_render", "rt_render_host", "rt_trace_primary", "rt_trace_primary_noalloc", "rt_quantize",
-           "rt_resolve_sums", "rt_render_guides", "rt_reconstruct", "rt_get_stats", "rt_last_error", "rt_version",
+           "rt_resolve_sums", "rt_render_guides", "rt_reconstruct", "rt_upscale", "rt_get_stats", "rt_last_error", "rt_version",
            "rt_decode_jpeg", "rt_load_jpeg_file", "rt_free_image", "rt_image_last_error", "rt_write_ppm"]
 
 
@@ -119,6 +119,8 @@ def lib():
         L.rt_resolve_sums.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]
         L.rt_render_guides.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
         L.rt_reconstruct.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(ReconstructParams), C.c_void_p]
+        L.rt_upscale.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32,
+                                 C.POINTER(ReconstructParams), C.c_void_p]
         L.rt_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
         L.rt_last_error.argtypes = [C.c_void_p]
         L.rt_last_error.restype = C.c_char_p
@@ -308,6 +310,15 @@ class Context:
         p.iterations, p.sigma_color, p.sigma_normal, p.sigma_depth, p.albedo_floor = iterations, sigma_color, sigma_normal, sigma_depth, albedo_floor
         self._check(lib().rt_reconstruct(self._h, C.c_void_p(rgba_device_ptr), C.c_void_p(guides_device_ptr), width, height,
                                          C.byref(p), C.c_void_p(out_device_ptr)))
+
+    def upscale(self, rgba_low_ptr, guides_low_ptr, low_width, low_height, guides_high_ptr, width, height, out_device_ptr,
+                sigma_normal=0.0, sigma_depth=0.0, albedo_floor=0.0):
+        """Joint bilateral upsampling of a low-resolution frame onto the grid of high-resolution guides (rt_upscale)."""
+        p = ReconstructParams()
+        p.struct_size = C.sizeof(ReconstructParams)
+        p.sigma_normal, p.sigma_depth, p.albedo_floor = sigma_normal, sigma_depth, albedo_floor
+        self._check(lib().rt_upscale(self._h, C.c_void_p(rgba_low_ptr), C.c_void_p(guides_low_ptr), low_width, low_height,
+                                     C.c_void_p(guides_high_ptr), width, height, C.byref(p), C.c_void_p(out_device_ptr)))
 
     def stats(self):
         s = Stats()

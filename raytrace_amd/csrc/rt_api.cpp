@@ -833,6 +833,36 @@ int rt_reconstruct(rt_context* ctx, const float* rgba_device, const float* guide
     return RT_OK;
 }
 
+int rt_upscale(rt_context* ctx, const float* rgba_low_device, const float* guides_low_device, int32_t low_width, int32_t low_height,
+               const float* guides_high_device, int32_t width, int32_t height, const rt_reconstruct_params* p, float* rgba_out_device) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (p && p->struct_size != sizeof(rt_reconstruct_params)) return fail(ctx, RT_ERR_INVALID, "rt_reconstruct_params: struct_size mismatch");
+    if (low_width < 2 || low_height < 2 || width < 2 || height < 2 || width > 65536 || height > 65536)
+        return fail(ctx, RT_ERR_INVALID, "rt_upscale: sizes must be in [2, 65536]");
+    if (width < low_width || height < low_height || width > 4 * low_width || height > 4 * low_height)
+        return fail(ctx, RT_ERR_INVALID, "rt_upscale: the high resolution must be 1 to 4 times the low one per axis");
+    if (!rgba_low_device || !guides_low_device || !guides_high_device || !rgba_out_device) return fail(ctx, RT_ERR_INVALID, "rt_upscale: null buffer");
+    rt::DReconstruct rp{};
+    rp.width = width; rp.height = height; rp.iterations = 0; rp.sigma_color = 0.0f;
+    rp.sigma_normal = p && p->sigma_normal != 0.0f ? p->sigma_normal : 16.0f;
+    rp.sigma_depth = p && p->sigma_depth != 0.0f ? p->sigma_depth : 0.05f;
+    rp.albedo_floor = p && p->albedo_floor != 0.0f ? p->albedo_floor : 0.02f;
+    if (!(rp.sigma_normal > 0.0f) || !(rp.sigma_depth > 0.0f) || !(rp.albedo_floor > 0.0f) || !std::isfinite(rp.sigma_normal) ||
+        !std::isfinite(rp.sigma_depth) || !std::isfinite(rp.albedo_floor))
+        return fail(ctx, RT_ERR_INVALID, "rt_upscale: sigmas and albedo_floor must be finite and positive");
+    DeviceGuard g(ctx->device);
+    const size_t nl = (size_t)low_width * low_height, nh = (size_t)width * height;
+    int rc;
+    if ((rc = check_device_range(ctx, rgba_low_device, nl * sizeof(float4), "rt_upscale (low frame)")) ||
+        (rc = check_device_range(ctx, guides_low_device, nl * 2 * sizeof(float4), "rt_upscale (low guides)")) ||
+        (rc = check_device_range(ctx, guides_high_device, nh * 2 * sizeof(float4), "rt_upscale (high guides)")) ||
+        (rc = check_device_range(ctx, rgba_out_device, nh * sizeof(float4), "rt_upscale (result)"))) return rc;
+    RT_HIP(ctx, rt::launch_upscale(rp, low_width, low_height, reinterpret_cast<const float4*>(rgba_low_device),
+                                   reinterpret_cast<const float4*>(guides_low_device), reinterpret_cast<const float4*>(guides_high_device),
+                                   reinterpret_cast<float4*>(rgba_out_device), ctx->stream));
+    return RT_OK;
+}
+
 int rt_get_stats(rt_context* ctx, rt_stats* out) {
     if (!ctx || !out) return RT_ERR_INVALID;
     // the caller says how large its rt_stats is; fields added after its header was written are not

@@ -163,4 +163,8 @@ struct DReconstruct {
 hipError_t launch_reconstruct(const DReconstruct& rp, const float4* rgba, const float4* guides, float4* tmp, float4* out,
                               hipStream_t stream);
 
+// rp.width / rp.height: the high resolution; the sigmas and the albedo floor as in launch_reconstruct
+hipError_t launch_upscale(const DReconstruct& rp, int low_width, int low_height, const float4* rgba_low, const float4* guides_low,
+                          const float4* guides_high, float4* out, hipStream_t stream);
+
 }  // namespace rt

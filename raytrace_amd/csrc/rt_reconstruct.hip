@@ -85,7 +85,68 @@ __global__ __launch_bounds__(kThreads) void atrous_kernel(const float4* __restri
     cout[at] = r;
 }
 
+// Joint bilateral upsampling (Kopf, Cohen, Lischinski, Uyttendaele 2007) of a low-resolution frame onto the
+// pixel grid of guides rendered at the high resolution: a high-resolution pixel takes the 3x3 low-resolution
+// pixels around its own position (tent weights of width 1.5 low pixels), each counted by how well the first hit
+// of ITS centre ray agrees with the first hit of the high-resolution pixel's (same object, normal, distance), on
+// colours divided by the low-resolution albedo; the result is multiplied by the HIGH-resolution albedo, so
+// texture detail and silhouettes come from the high-resolution guides.  A pixel none of whose neighbours
+// agrees (a feature thinner than a low-resolution pixel) falls back to the tent weights alone.
+// Pixel centres map as main.cc:117-118 places them: s = (x + 0.5) / (W - 1) on either grid.
+__global__ __launch_bounds__(kThreads) void upscale_kernel(const float4* __restrict__ clow, const float4* __restrict__ g0l,
+                                                           const float4* __restrict__ g1l, int lw, int lh,
+                                                           const float4* __restrict__ g0h, const float4* __restrict__ g1h, int hw, int hh,
+                                                           float sigma_normal, float inv_sigma_depth, float albedo_floor,
+                                                           float4* __restrict__ out) {
+    const int x = blockIdx.x * kTileW + (threadIdx.x % kTileW), y = blockIdx.y * kTileH + (threadIdx.x / kTileW);
+    if (x >= hw || y >= hh) return;
+    const long long at = (long long)y * hw + x;
+    const float4 gp = g0h[at], ap = g1h[at];
+    const int idp = __float_as_int(ap.w);
+    const bool hit = idp >= 0;
+    const float ux = ((float)x + 0.5f) * ((float)(lw - 1) / (float)(hw - 1)) - 0.5f;
+    const float uy = ((float)y + 0.5f) * ((float)(lh - 1) / (float)(hh - 1)) - 0.5f;
+    const int bx = (int)floorf(ux + 0.5f), by = (int)floorf(uy + 0.5f);      // nearest low-resolution pixel
+    const float k_depth = hit ? -1.4426950408889634f * inv_sigma_depth / fmaxf(gp.w, 1.0e-6f) : 0.0f;
+    const float k_normal = hit ? sigma_normal : 0.0f;
+    float ax = 0.0f, ay = 0.0f, az = 0.0f, wsum = 0.0f, bx_ = 0.0f, by_ = 0.0f, bz_ = 0.0f, bsum = 0.0f, spp = 0.0f;
+#pragma unroll
+    for (int dy = -1; dy <= 1; dy++) {
+#pragma unroll
+        for (int dx = -1; dx <= 1; dx++) {
+            const int qx = min(max(bx + dx, 0), lw - 1), qy = min(max(by + dy, 0), lh - 1);
+            const float tent = fmaxf(1.0f - fabsf((float)(bx + dx) - ux) * (1.0f / 1.5f), 0.0f) *
+                               fmaxf(1.0f - fabsf((float)(by + dy) - uy) * (1.0f / 1.5f), 0.0f);
+            const long long q = (long long)qy * lw + qx;
+            const float4 cq = clow[q], gq = g0l[q], aq = g1l[q];
+            const float inv = 1.0f / fmaxf(cq.w, 1.0f);
+            const float rx = cq.x * inv / fmaxf(aq.x, albedo_floor), ry = cq.y * inv / fmaxf(aq.y, albedo_floor),
+                        rz = cq.z * inv / fmaxf(aq.z, albedo_floor);
+            if (dx == 0 && dy == 0) spp = cq.w;
+            bx_ = fmaf(tent, rx, bx_); by_ = fmaf(tent, ry, by_); bz_ = fmaf(tent, rz, bz_); bsum += tent;
+            if (__float_as_int(aq.w) != idp) continue;
+            const float cosn = fminf(fmaxf(fmaf(gp.z, gq.z, fmaf(gp.y, gq.y, gp.x * gq.x)), 1.0e-6f), 1.0f);
+            const float w = tent * __builtin_amdgcn_exp2f(fmaf(k_normal, __builtin_amdgcn_logf(cosn), k_depth * fabsf(gp.w - gq.w)));
+            ax = fmaf(w, rx, ax); ay = fmaf(w, ry, ay); az = fmaf(w, rz, az); wsum += w;
+        }
+    }
+    const bool agreed = wsum > 1.0e-4f;
+    const float inv = 1.0f / (agreed ? wsum : bsum);         // (the centre tap's tent weight is at least 4/9)
+    const float sx = (agreed ? ax : bx_) * inv, sy = (agreed ? ay : by_) * inv, sz = (agreed ? az : bz_) * inv;
+    out[at] = make_float4(sx * fmaxf(ap.x, albedo_floor) * spp, sy * fmaxf(ap.y, albedo_floor) * spp, sz * fmaxf(ap.z, albedo_floor) * spp, spp);
+}
+
 }  // namespace
+
+hipError_t launch_upscale(const DReconstruct& rp, int low_width, int low_height, const float4* rgba_low, const float4* guides_low,
+                          const float4* guides_high, float4* out, hipStream_t stream) {
+    const long long nl = (long long)low_width * low_height, nh = (long long)rp.width * rp.height;
+    if (nl <= 0 || nh <= 0) return hipSuccess;
+    const dim3 grid((unsigned)((rp.width + kTileW - 1) / kTileW), (unsigned)((rp.height + kTileH - 1) / kTileH)), block(kThreads);
+    hipLaunchKernelGGL(upscale_kernel, grid, block, 0, stream, rgba_low, guides_low, guides_low + nl, low_width, low_height,
+                       guides_high, guides_high + nh, rp.width, rp.height, rp.sigma_normal, 1.0f / rp.sigma_depth, rp.albedo_floor, out);
+    return hipGetLastError();
+}
 
 hipError_t launch_reconstruct(const DReconstruct& rp, const float4* rgba, const float4* guides, float4* tmp, float4* out,
                               hipStream_t stream) {

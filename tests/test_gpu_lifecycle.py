@@ -153,7 +153,9 @@ def test_a_device_buffer_that_is_too_small_is_an_error_not_a_fault(api, rtiow_fl
                 lambda: c.render_guides(W, H, sums.value + 16),                 # two planes of float4: exactly the 32 bytes a pixel of `sums`
                 lambda: c.reconstruct(short.value, sums.value, W, H, full.value),
                 lambda: c.reconstruct(full.value, short.value, W, H, full.value),
-                lambda: c.reconstruct(full.value, sums.value, W, H, short.value)):
+                lambda: c.reconstruct(full.value, sums.value, W, H, short.value),
+                lambda: c.upscale(short.value, sums.value, W, H, sums.value, W, H, full.value),
+                lambda: c.upscale(full.value, sums.value, W, H, sums.value, W, H, short.value)):
         with pytest.raises(api.RtError) as e:
             bad()
         assert e.value.code == api.RT_ERR_INVALID and "bytes" in str(e.value)
