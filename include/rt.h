@@ -273,7 +273,10 @@ typedef struct rt_reconstruct_params {
     float sigma_normal;          /* 0 = default (16) */
     float sigma_depth;           /* 0 = default (0.05) */
     float albedo_floor;          /* 0 = default (0.02) */
+    uint32_t flags;              /* RT_RECON_NO_LDS: every pass reads its taps through the caches instead of staging the
+                                    close ones (steps 1, 2, 4) in LDS (same image; for comparison) */
 } rt_reconstruct_params;
+enum { RT_RECON_NO_LDS = 1u << 0 };
 int rt_render_guides(rt_context* ctx, int32_t width, int32_t height, float* guides_device);
 /* rt_upscale: a frame rendered at a low resolution onto a higher-resolution pixel grid (the "upscaler" half of
  *   README.md:7), by joint bilateral upsampling (Kopf, Cohen, Lischinski, Uyttendaele, SIGGRAPH 2007): a

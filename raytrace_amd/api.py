@@ -60,7 +60,10 @@ class RenderParams(C.Structure):
 
 class ReconstructParams(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("iterations", C.c_int32), ("sigma_color", C.c_float),
-                ("sigma_normal", C.c_float), ("sigma_depth", C.c_float), ("albedo_floor", C.c_float)]
+                ("sigma_normal", C.c_float), ("sigma_depth", C.c_float), ("albedo_floor", C.c_float), ("flags", C.c_uint32)]
+
+
+RT_RECON_NO_LDS = 1
 
 
 class Hit(C.Structure):
@@ -303,11 +306,12 @@ class Context:
         self._check(lib().rt_render_guides(self._h, width, height, C.c_void_p(guides_device_ptr)))
 
     def reconstruct(self, rgba_device_ptr, guides_device_ptr, width, height, out_device_ptr, iterations=0, sigma_color=0.0,
-                    sigma_normal=0.0, sigma_depth=0.0, albedo_floor=0.0):
+                    sigma_normal=0.0, sigma_depth=0.0, albedo_floor=0.0, flags=0):
         """Edge-avoiding a-trous reconstruction of a low-sample-count frame (rt_reconstruct); 0 = default."""
         p = ReconstructParams()
         p.struct_size = C.sizeof(ReconstructParams)
         p.iterations, p.sigma_color, p.sigma_normal, p.sigma_depth, p.albedo_floor = iterations, sigma_color, sigma_normal, sigma_depth, albedo_floor
+        p.flags = flags
         self._check(lib().rt_reconstruct(self._h, C.c_void_p(rgba_device_ptr), C.c_void_p(guides_device_ptr), width, height,
                                          C.byref(p), C.c_void_p(out_device_ptr)))
 

@@ -812,6 +812,7 @@ int rt_reconstruct(rt_context* ctx, const float* rgba_device, const float* guide
     rp.sigma_normal = p && p->sigma_normal != 0.0f ? p->sigma_normal : 16.0f;
     rp.sigma_depth = p && p->sigma_depth != 0.0f ? p->sigma_depth : 0.05f;
     rp.albedo_floor = p && p->albedo_floor != 0.0f ? p->albedo_floor : 0.02f;
+    rp.no_lds = p && (p->flags & RT_RECON_NO_LDS) ? 1 : 0;
     if (rp.iterations < 1 || rp.iterations > 8) return fail(ctx, RT_ERR_INVALID, "rt_reconstruct: iterations must be in [1, 8]");
     if (!(rp.sigma_color >= 0.0f) || !(rp.sigma_normal > 0.0f) || !(rp.sigma_depth > 0.0f) || !(rp.albedo_floor > 0.0f) ||
         !std::isfinite(rp.sigma_color) || !std::isfinite(rp.sigma_normal) || !std::isfinite(rp.sigma_depth) || !std::isfinite(rp.albedo_floor))

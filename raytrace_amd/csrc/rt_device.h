@@ -158,6 +158,7 @@ struct DReconstruct {
     int width, height, iterations;
     float sigma_color;        // <= 0: 1.6 / sqrt(samples of the pixel)
     float sigma_normal, sigma_depth, albedo_floor;
+    int no_lds;               // every pass through the caches (for comparison with the passes staged in LDS)
 };
 // tmp: two float4 images of the frame's size; in, out may be the same buffer
 hipError_t launch_reconstruct(const DReconstruct& rp, const float4* rgba, const float4* guides, float4* tmp, float4* out,

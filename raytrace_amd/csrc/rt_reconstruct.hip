@@ -85,6 +85,81 @@ __global__ __launch_bounds__(kThreads) void atrous_kernel(const float4* __restri
     cout[at] = r;
 }
 
+// The same pass for taps that stand close (steps 1, 2 and 4): the tile's neighbourhood, (32 + 4 step) x (8 + 4 step)
+// pixels, is staged once into LDS (eight planes: colour, normal, distance, object; 14 to 37 KB) with coalesced
+// loads, and the 25 taps of every pixel are LDS reads; through the caches each pixel was fetched 25 times over.
+// Pixels beyond the image carry an object number no pixel has, so they fail the first test like any tap on
+// another object.  Same arithmetic in the same order as atrous_kernel: the two give the same bits.
+constexpr int kNoPixel = (int)0x80000000;
+template <bool LAST>
+__global__ __launch_bounds__(kThreads) void atrous_lds_kernel(const float4* __restrict__ cin, const float4* __restrict__ g0,
+                                                              const float4* __restrict__ g1, int width, int height, int step,
+                                                              float sigma_color, float pass_scale, float sigma_normal,
+                                                              float inv_sigma_depth, float albedo_floor, int band_rows, int tiles_x,
+                                                              float4* __restrict__ cout) {
+    extern __shared__ float s_tile[];
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int ty = xcd * band_rows + slot / tiles_x, tx = slot % tiles_x;
+    if (slot / tiles_x >= band_rows) return;
+    const int halo = 2 * step, rw = kTileW + 2 * halo, rh = kTileH + 2 * halo, rn = rw * rh;
+    float* pc0 = s_tile; float* pc1 = pc0 + rn; float* pc2 = pc1 + rn;
+    float* pn0 = pc2 + rn; float* pn1 = pn0 + rn; float* pn2 = pn1 + rn;
+    float* pt = pn2 + rn;
+    int* pid = reinterpret_cast<int*>(pt + rn);
+    const int x0 = tx * kTileW - halo, y0 = ty * kTileH - halo;
+    for (int i = threadIdx.x; i < rn; i += kThreads) {
+        const int qx = x0 + i % rw, qy = y0 + i / rw;
+        if (qx >= 0 && qx < width && qy >= 0 && qy < height) {
+            const long long q = (long long)qy * width + qx;
+            const float4 c = cin[q], g = g0[q];
+            pc0[i] = c.x; pc1[i] = c.y; pc2[i] = c.z;
+            pn0[i] = g.x; pn1[i] = g.y; pn2[i] = g.z; pt[i] = g.w;
+            pid[i] = __float_as_int(g1[q].w);
+        } else {
+            pid[i] = kNoPixel;
+        }
+    }
+    __syncthreads();
+    const int lx = threadIdx.x % kTileW, ly = threadIdx.x / kTileW;
+    const int x = tx * kTileW + lx, y = ty * kTileH + ly;
+    if (x >= width || y >= height) return;
+    const long long at = (long long)y * width + x;
+    const int ci = (ly + halo) * rw + lx + halo;
+    const float cpx = pc0[ci], cpy = pc1[ci], cpz = pc2[ci], gpx = pn0[ci], gpy = pn1[ci], gpz = pn2[ci], gpw = pt[ci];
+    const int idp = pid[ci];
+    const float spp = cin[at].w;
+    const bool hit = idp >= 0;
+    const float sc = sigma_color > 0.0f ? sigma_color : 1.6f * __builtin_amdgcn_rsqf(fmaxf(spp, 1.0f));
+    const float k_color = -1.4426950408889634f * pass_scale / (sc * sc);
+    const float k_depth = hit ? -1.4426950408889634f * inv_sigma_depth / fmaxf(gpw, 1.0e-6f) : 0.0f;
+    const float k_normal = hit ? sigma_normal : 0.0f;
+    const float b3[5] = {0.0625f, 0.25f, 0.375f, 0.25f, 0.0625f};
+    float ax = 0.0f, ay = 0.0f, az = 0.0f, wsum = 0.0f;
+#pragma unroll
+    for (int dy = -2; dy <= 2; dy++) {
+#pragma unroll
+        for (int dx = -2; dx <= 2; dx++) {
+            const int q = ci + (dy * rw + dx) * step;
+            if (pid[q] != idp) continue;
+            const float cqx = pc0[q], cqy = pc1[q], cqz = pc2[q];
+            const float cosn = fminf(fmaxf(fmaf(gpz, pn2[q], fmaf(gpy, pn1[q], gpx * pn0[q])), 1.0e-6f), 1.0f);
+            const float ex = cqx - cpx, ey = cqy - cpy, ez = cqz - cpz;
+            const float d2 = fmaf(ez, ez, fmaf(ey, ey, ex * ex));
+            const float e = fmaf(k_normal, __builtin_amdgcn_logf(cosn), fmaf(k_depth, fabsf(gpw - pt[q]), k_color * d2));
+            const float w = b3[dy + 2] * b3[dx + 2] * __builtin_amdgcn_exp2f(e);
+            ax = fmaf(w, cqx, ax); ay = fmaf(w, cqy, ay); az = fmaf(w, cqz, az);
+            wsum += w;
+        }
+    }
+    const float inv = 1.0f / wsum;
+    float4 r = make_float4(ax * inv, ay * inv, az * inv, spp);
+    if (LAST) {
+        const float4 a = g1[at];
+        r.x *= fmaxf(a.x, albedo_floor) * spp; r.y *= fmaxf(a.y, albedo_floor) * spp; r.z *= fmaxf(a.z, albedo_floor) * spp;
+    }
+    cout[at] = r;
+}
+
 // Joint bilateral upsampling (Kopf, Cohen, Lischinski, Uyttendaele 2007) of a low-resolution frame onto the
 // pixel grid of guides rendered at the high resolution: a high-resolution pixel takes the 3x3 low-resolution
 // pixels around its own position (tent weights of width 1.5 low pixels), each counted by how well the first hit
@@ -165,7 +240,16 @@ hipError_t launch_reconstruct(const DReconstruct& rp, const float4* rgba, const 
     for (int it = 0; it < rp.iterations; it++, scale *= 4.0f) {
         const bool last = it == rp.iterations - 1;
         float4* dst = last ? out : b;
-        if (last)
+        const int step = 1 << it;
+        if (step <= 4 && !rp.no_lds) {
+            const size_t lds = (size_t)(kTileW + 4 * step) * (kTileH + 4 * step) * 8 * sizeof(float);
+            if (last)
+                hipLaunchKernelGGL(atrous_lds_kernel<true>, grid, block, lds, stream, a, g0, g1, rp.width, rp.height, step, rp.sigma_color, scale,
+                                   rp.sigma_normal, 1.0f / rp.sigma_depth, rp.albedo_floor, band_rows, tiles_x, dst);
+            else
+                hipLaunchKernelGGL(atrous_lds_kernel<false>, grid, block, lds, stream, a, g0, g1, rp.width, rp.height, step, rp.sigma_color, scale,
+                                   rp.sigma_normal, 1.0f / rp.sigma_depth, rp.albedo_floor, band_rows, tiles_x, dst);
+        } else if (last)
             hipLaunchKernelGGL(atrous_kernel<true>, grid, block, 0, stream, a, g0, g1, rp.width, rp.height, 1 << it, rp.sigma_color, scale,
                                rp.sigma_normal, 1.0f / rp.sigma_depth, rp.albedo_floor, band_rows, tiles_x, dst);
         else

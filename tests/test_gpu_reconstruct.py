@@ -84,6 +84,11 @@ def test_reconstruction_matches_the_restatement_and_raises_psnr(api, oracle, rti
         err = np.abs(got[..., :3] - want[..., :3]) / spp
         assert err.max() <= 1e-4 * max(1.0, float(want[..., :3].max() / spp)), (spp, float(err.max()))
         gains[spp] = (R.psnr(low, high, spp, 1024), R.psnr(got, high, spp, 1024))
+        # the passes staged in LDS and the passes through the caches do the same arithmetic in the same order
+        for it in (1, 3, 4, 6):
+            a, _ = _reconstruct(api, ctx, low, g, W, H, iterations=it)
+            b, _ = _reconstruct(api, ctx, low, g, W, H, iterations=it, flags=api.RT_RECON_NO_LDS)
+            assert np.array_equal(a, b), (spp, it)
         # in place: the same answer when the result overwrites the frame
         ctx.reconstruct(src.data_ptr(), g.data_ptr(), W, H, src.data_ptr())
         ctx.stats()

@@ -30,9 +30,14 @@ for spp in (4, 16):
         ctx.reconstruct(low.data_ptr(), g.data_ptr(), W, H, out.data_ptr()); ev[2].record()
         torch.cuda.synchronize()
     t_g, t_r = ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2])
+    for rep in range(3):
+        torch.cuda.synchronize()
+        ev[0].record(); ctx.reconstruct(low.data_ptr(), g.data_ptr(), W, H, out.data_ptr(), flags=api.RT_RECON_NO_LDS); ev[1].record()
+        torch.cuda.synchronize()
+    t_direct = ev[0].elapsed_time(ev[1])
     passes = 4
     algo = W * H * (32 + 16 + passes * (36 + 16))          # demodulate + passes, bytes in and out once each
     print(f"{spp:3d} spp frame {t_low:7.3f} ms | guides {t_g:6.3f} ms | reconstruct ({passes} passes) {t_r:6.3f} ms = "
-          f"{algo / t_r / 1e6:7.1f} GB/s of algorithmic bytes | PSNR against 256 spp: {R.psnr(low.cpu().numpy(), high.cpu().numpy(), spp, 256):.2f} -> "
+          f"{algo / t_r / 1e6:7.1f} GB/s of algorithmic bytes (every pass through the caches: {t_direct:6.3f} ms) | PSNR against 256 spp: {R.psnr(low.cpu().numpy(), high.cpu().numpy(), spp, 256):.2f} -> "
           f"{R.psnr(out.cpu().numpy(), high.cpu().numpy(), spp, 256):.2f} dB", flush=True)
 ctx.close()
