@@ -220,13 +220,14 @@ class Workload:
         self.depth, self.seed = 50, 1
         self.accel = api.RT_ACCEL_BVH
         self.path = False                       # the camera moves from step to step
-        if name in ("c2", "c5"):
-            self.W, self.H, self.spp = 1920, 1080, 100 if name == "c2" else 256
+        if name in ("c1", "c2", "c5"):
+            self.W, self.H, self.spp = (1200, 800, 500) if name == "c1" else (1920, 1080, 100 if name == "c2" else 256)
             self.flat = S.flatten(S.rtiow_scene())
             self.camera = S.rtiow_camera(float(np.float32(self.W / self.H)))
             self.n_spheres, self.n_rects = 487, 0
             self.path = name == "c5"
-            self.label = ("configs[1]: RTIOW random-spheres scene (the reference's default world, 487 spheres, "
+            self.label = ("configs[0] on the GPU: the frame main.cc renders by default, 1200x800 @500spp depth 50 (main.cc:90-106)" if name == "c1" else
+                          "configs[1]: RTIOW random-spheres scene (the reference's default world, 487 spheres, "
                           "g++ build) 1920x1080 @100spp depth 50" if name == "c2" else
                           "configs[4]: camera-path sequence (cuda/main.cu:220-279) over the RTIOW scene, "
                           "1920x1080 @256spp depth 50, one frame per step")
@@ -654,7 +655,7 @@ def main():
         del fbufs
         torch.cuda.empty_cache()
         sp = torch.cuda.current_stream().cuda_stream
-        other = {"c3": lone_frames("c3", device, sp, 3), "c4": lone_frames("c4", device, sp, 3), "c5": lone_frames("c5", device, sp, 1),
+        other = {"c1": lone_frames("c1", device, sp, 3), "c3": lone_frames("c3", device, sp, 3), "c4": lone_frames("c4", device, sp, 3), "c5": lone_frames("c5", device, sp, 1),
                  "reconstruction": reconstruction_stage(device, sp)}
 
     if rank == 0:

@@ -75,6 +75,40 @@ def test_stratified_sample_of_the_frame_agrees_with_the_checker(frames, oracle, 
     assert (np.abs(got - want).max(axis=2) > 1e-5).mean() < 0.02
 
 
+def test_reference_default_frame_against_the_compiled_reference(api, rtiow_flat, reference):
+    """configs[0] on the GPU: the frame main.cc renders by default (1200x800, 500 samples per pixel, depth 50,
+    main.cc:90-106).  The whole frame is bit-identical under the tree walk and the scan and adds up from integer
+    sample windows; every 16th pixel of every 16th row at the first 8 samples is rendered by the compiled main.cc
+    itself from the same keyed stream and agrees to the bounds of the golden frames (RMSE of mean radiance 5e-4,
+    under 2 % of the pixels off by more than 1e-5, ray count of those samples within 1 %)."""
+    from raytrace_amd import scene as S
+    W1, H1, spp = 1200, 800, 500
+    cam = S.rtiow_camera(1.5).desc()
+    P = api.Context.params
+    frames, rays = [], []
+    for accel in (api.RT_ACCEL_BVH, api.RT_ACCEL_LIST):
+        c = api.Context(0)
+        c.upload_scene(rtiow_flat, accel=accel)
+        c.set_camera(**cam)
+        frames.append(c.render_host(P(W1, H1, spp, 50, 1)))
+        rays.append(c.stats()["rays"])
+        if accel == api.RT_ACCEL_BVH:
+            a = c.render_host(P(W1, H1, 200, 50, 1, flags=api.RT_FLAG_FIXED_SUMS))
+            a += c.render_host(P(W1, H1, 300, 50, 1, sample_begin=200, flags=api.RT_FLAG_FIXED_SUMS))
+            assert np.array_equal((a[..., :3].astype(np.float64) * 2.0 ** -32).astype(np.float32), frames[0][..., :3])
+            low = c.render_host(P(W1, H1, 8, 50, 1))
+        c.close()
+    assert np.array_equal(frames[0], frames[1]) and rays[0] == rays[1]
+    assert (frames[0][..., 3] == spp).all() and 2.5 < rays[0] / (W1 * H1 * spp) < 3.0      # main.cc: 2.73 rays per sample
+    reference.load_scene(S.rtiow_records())
+    reference.set_camera(**cam)
+    want, _ = reference.render_keyed(W1, H1, 8, 50, 1, step=(16, 16))
+    got, ref = low[::16, ::16, :3].astype(np.float64) / 8, want[::16, ::16] / 8
+    assert ref.sum() > 0
+    assert np.sqrt(np.mean((got - ref) ** 2)) <= 5e-4, np.sqrt(np.mean((got - ref) ** 2))
+    assert (np.abs(got - ref).max(axis=2) > 1e-5).mean() < 0.02
+
+
 def test_cornell_frame_at_1000_samples_adds_up_and_reassembles(api):
     """The Cornell configuration at its own size and sample count (1920x1080, 1000 samples per
     pixel, depth 50): the frame equals the sum of two windows of its samples taken as integer sums
