@@ -1,13 +1,13 @@
 """One scene of tests/test_gpu_fuzz.py::test_random_sphere_field again: image difference between the GPU
 frame and the double-precision restatement's, by depth limit (a chaotic scene parts from double
 precision after some specular bounces; up to depth limit 2 no pixel may differ).
-usage: python tools/field_case.py SEED"""
+usage: python tests/replay/field_case.py SEED"""
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 

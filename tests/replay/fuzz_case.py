@@ -1,12 +1,12 @@
 """One scene of tests/test_gpu_fuzz.py::test_random_scene again, with the rays whose closest hit
 differs most from the double-precision restatement printed in full (ray, object record, both
-distances, both normals).  python tools/fuzz_case.py SEED [n_worst]"""
+distances, both normals).  python tests/replay/fuzz_case.py SEED [n_worst]"""
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 

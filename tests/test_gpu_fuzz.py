@@ -215,7 +215,7 @@ def test_random_sphere_field(seed, oracle):
     rays = np.asarray(rays, np.float64).astype(np.float32).astype(np.float64)
     want = oracle.trace(flat, rays, t_min=0.001)
     # depth limits: 3 and 8, where single precision decides every branch of a path like the double-precision
-    # checker (tools/field_case.py: no pixel differs up to 8) and the strict bounds hold, and 50
+    # checker (tests/replay/field_case.py: no pixel differs up to 8) and the strict bounds hold, and 50
     W, H, spp, depth = 60, 40, 4, (50 if seed in _KEPT_FIELDS else int(rng.choice([3, 8, 50])))
     sums, n_rays = oracle.render(flat, cd, W, H, spp, depth, 9 + seed, threads=8)
     first = None
@@ -267,7 +267,7 @@ def test_random_sphere_field(seed, oracle):
         # relative sd of 1e-3 at 27 648 samples, largest 4.9e-3; this test's 9 600 samples scatter twice as much)
         assert abs(st["rays"] - n_rays) <= max(40, (4e-3 if depth <= 8 else 3e-2) * n_rays), (accel, depth, st["rays"], n_rays)
         peak = max(1.0, float(sums.max() / spp))
-        # (at depth limit 50 one scene in 37 000 reached 0.066 of the peak, the kept one: tools/field_case.py shows
+        # (at depth limit 50 one scene in 37 000 reached 0.066 of the peak, the kept one: tests/replay/field_case.py shows
         # it by depth limit; the wider bound is that scene's alone)
         bound = 0.02 if depth <= 8 else (0.09 if seed in _KEPT_FIELDS else 0.06)
         assert np.sqrt(np.mean((img[..., :3] / spp - sums / spp) ** 2)) <= bound * peak, (accel, depth)

@@ -9,7 +9,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np                                # noqa: E402
 import torch                                      # noqa: E402
 from raytrace_amd import api, scene as S          # noqa: E402
-from oracle import reconstruct as R               # noqa: E402  (PSNR helper only)
+
+
+def psnr(img, ref, spp_img, spp_ref):
+    """PSNR of the displayed frames (mean radiance through gamma 2 and the clamp of color.h:17-23, peak 1)."""
+    shown = lambda x, n: torch.sqrt(torch.clamp(x[..., :3] / n, 0.0, 1.0))
+    return float(-10.0 * torch.log10(torch.mean((shown(img, spp_img) - shown(ref, spp_ref)) ** 2)))
+
 
 W, H = 1920, 1080
 ctx = api.Context(0)
@@ -38,6 +44,6 @@ for spp in (4, 16):
     passes = 4
     algo = W * H * (32 + 16 + passes * (36 + 16))          # demodulate + passes, bytes in and out once each
     print(f"{spp:3d} spp frame {t_low:7.3f} ms | guides {t_g:6.3f} ms | reconstruct ({passes} passes) {t_r:6.3f} ms = "
-          f"{algo / t_r / 1e6:7.1f} GB/s of algorithmic bytes (every pass through the caches: {t_direct:6.3f} ms) | PSNR against 256 spp: {R.psnr(low.cpu().numpy(), high.cpu().numpy(), spp, 256):.2f} -> "
-          f"{R.psnr(out.cpu().numpy(), high.cpu().numpy(), spp, 256):.2f} dB", flush=True)
+          f"{algo / t_r / 1e6:7.1f} GB/s of algorithmic bytes (every pass through the caches: {t_direct:6.3f} ms) | PSNR against 256 spp: {psnr(low, high, spp, 256):.2f} -> "
+          f"{psnr(out, high, spp, 256):.2f} dB", flush=True)
 ctx.close()
