@@ -13,11 +13,13 @@
            1920x1080 @256 spp, a different camera and seed every step
 
 --partition (N > 1)
-  tiles            rank g renders the interleaved 4-row tiles g, g+N, ...; rank 0 gathers the
-                   partial framebuffers over RCCL inside the timed region
+  tiles            rank g renders the interleaved 4-row tiles g, g+N, ...; the partial framebuffers
+                   are gathered over RCCL inside the timed region, step k's on rank k % N (the receive
+                   side of the gather and the row index are shared out like the rendering;
+                   --gather-root 0: always on rank 0)
   samples          rank g renders the whole frame for its share of the samples as integer sums
-                   (RT_FLAG_FIXED_SUMS); an int64 RCCL reduce to rank 0 and rt_resolve_sums give
-                   the frame, bit for bit the single-GPU one
+                   (RT_FLAG_FIXED_SUMS); an int64 RCCL reduce (to rank k % N for step k) and
+                   rt_resolve_sums give the frame, bit for bit the single-GPU one
   frames+samples   (c5) frames are dealt to the ranks in rounds of N, no exchange; the frames of
                    a last, incomplete round are sample-split over all ranks as above
 
@@ -352,6 +354,9 @@ def main():
     ap.add_argument("--rehearse-collectives", action="store_true",
                     help="with one rank: set the process group up all the same and send every frame through the partition's "
                          "collectives (a gather or an integer reduce among one rank), so that the RCCL code path runs on a one-GPU box")
+    ap.add_argument("--gather-root", choices=["rotate", "0"], default="rotate",
+                    help="which rank assembles step k's frame (tiles, samples): k %% N, so that the gather's receive side, the row "
+                         "index and the resolve are shared out like the rendering, or always rank 0")
     ap.add_argument("--check", action="store_true",
                     help="rank 0 also renders every timed frame alone and compares it bit for bit with the assembled one")
     args = ap.parse_args()
@@ -386,9 +391,10 @@ def main():
         # the first collectives on a communicator set up its peer connections: done here, untimed,
         # whatever --warmup is
         probe = torch.zeros(16, device=comm_dev)
-        dist.gather(probe, [torch.empty_like(probe) for _ in range(world)] if rank == 0 else None, dst=0)
         probe_i = torch.zeros(16, dtype=torch.int64, device=comm_dev)
-        dist.reduce(probe_i, dst=0)
+        for root in range(world if args.gather_root == "rotate" else 1):
+            dist.gather(probe, [torch.empty_like(probe) for _ in range(world)] if rank == root else None, dst=root)
+            dist.reduce(probe_i, dst=root)
         dist.barrier()
 
     wl = Workload(args.config, args.spp)
@@ -425,6 +431,10 @@ def main():
     # reduce + resolve.  mode "own": the whole frame on one rank, nothing exchanged (frame-parallel
     # rounds of c5; and every step of a single-GPU run).
     full_rounds = (args.steps // world) * world if partition == "frames+samples" else 0
+
+    def root_of(k):
+        """The rank that ends up with step k's frame when the ranks share it."""
+        return k % world if args.gather_root == "rotate" else 0
 
     def plan(k, n_steps):
         if not dist_on:
@@ -483,19 +493,19 @@ def main():
         c, i = k % n_ctx, k % n_buf
         mode, owner = plan(k, n_steps)
         main_stream.wait_event(rendered[i])
-        frame = None
+        frame, root = None, root_of(k)
         if mode == "tiles":
-            frame = rdist.gather_frame(fbufs[i].cpu() if args.backend == "gloo" else fbufs[i], H, TILE_ROWS, rank, world,
+            frame = rdist.gather_frame(fbufs[i].cpu() if args.backend == "gloo" else fbufs[i], H, TILE_ROWS, rank, world, dst=root,
                                        always=args.rehearse_collectives)
         elif mode == "samples":
             if args.backend == "gloo":
                 host = ibufs[i].cpu()
-                rdist.reduce_sums(host, rank, world, always=args.rehearse_collectives)
-                if rank == 0:
+                rdist.reduce_sums(host, rank, world, dst=root, always=args.rehearse_collectives)
+                if rank == root:
                     ibufs[i].copy_(host)
             else:
-                rdist.reduce_sums(ibufs[i], rank, world, always=args.rehearse_collectives)
-            if rank == 0:
+                rdist.reduce_sums(ibufs[i], rank, world, dst=root, always=args.rehearse_collectives)
+            if rank == root:
                 post.resolve_sums(ibufs[i].data_ptr(), W * H, fbufs[i].data_ptr())
                 if wl.path:
                     post.quantize(fbufs[i].data_ptr(), W * H, SPP, rgb8[i].data_ptr())
@@ -662,9 +672,10 @@ def main():
         if not dist_on:
             how = "single GPU"
         elif partition == "tiles":
-            how = f"row-tiles x{world}, RCCL gather to rank 0"
+            how = f"row-tiles x{world}, RCCL gather to rank " + ("k % N (step k)" if args.gather_root == "rotate" and world > 1 else "0")
         elif partition == "samples":
-            how = f"sample-split x{world} as integer sums, RCCL int64 reduce to rank 0 + resolve"
+            how = (f"sample-split x{world} as integer sums, RCCL int64 reduce to rank " +
+                   ("k % N (step k)" if args.gather_root == "rotate" and world > 1 else "0") + " + resolve")
         else:
             how = (f"frames dealt in rounds of {world} ({full_rounds} of {args.steps} steps), the other "
                    f"{args.steps - full_rounds} sample-split x{world} (integer sums, int64 reduce)")

@@ -35,6 +35,9 @@ def test_two_ranks_assemble_the_single_gpu_frame():
     assert res["n_gpus"] == 2 and res["frame_matches_single_gpu"] is True
     assert res["config"]["rays_per_frame"] > 5.0e8 and res["value"] > 0
     assert "roofline" in res and res["roofline"]["frac"] > 0
+    assert "k % N" in res["config"]["partition"]                      # step k's frame is assembled on rank k % N ...
+    res = _bench("--steps", "3", "--warmup", "1", "--gather-root", "0", "--spp", "16")
+    assert res["frame_matches_single_gpu"] is True and "rank 0" in res["config"]["partition"]   # ... or always on rank 0
 
 
 def test_two_ranks_cornell_tiles_and_sample_split():
