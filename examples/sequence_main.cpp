@@ -9,7 +9,11 @@
 //
 //   g++ -O2 -std=c++17 -D__HIP_PLATFORM_AMD__ -Iinclude -I/opt/rocm/include examples/sequence_main.cpp
 //       -Lraytrace_amd -lrt_amd -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,$PWD/raytrace_amd -o sequence
-//   ./sequence scene.txt out_dir 1920 1080 256 0 240 [p3|p6]
+//   ./sequence scene.txt out_dir 1920 1080 256 0 240 [p3|p6] [recon]
+//
+// recon: every frame goes through the low-to-high sample-count reconstruction stage before it is quantised
+// (rt_render_guides + rt_reconstruct: what the reference's README.md:7 names as ongoing work for the frame
+// pairs of cuda/main.cu:557-576) and is written as image_<frame>_recon.ppm.
 //
 // scene.txt: one sphere per line, as examples/rtiow_main.cpp reads it.
 #include <hip/hip_runtime_api.h>
@@ -47,11 +51,12 @@ static sceneobject_list load_world(const char* path) {
     std::cerr << #call << ": " << rt_last_error(ctx) << "\n"; return 1; } } while (0)
 
 int main(int argc, char** argv) {
-    if (argc < 8) { std::cerr << "usage: sequence scene.txt out_dir width height spp first_frame n_frames [p3|p6]\n"; return 2; }
+    if (argc < 8) { std::cerr << "usage: sequence scene.txt out_dir width height spp first_frame n_frames [p3|p6] [recon]\n"; return 2; }
     const std::string out_dir = argv[2];
     const int W = std::atoi(argv[3]), H = std::atoi(argv[4]), spp = std::atoi(argv[5]);
     const int first = std::atoi(argv[6]), n_frames = std::atoi(argv[7]);
     const bool text = argc < 9 || std::string(argv[8]) != "p6";
+    const bool recon = argc >= 10 && std::string(argv[9]) == "recon";
     const int ray_bounce_limit = 25;                       // cuda/main.cu:452
     const uint64_t seed = 1;
     if (W < 1 || H < 1 || spp < 1 || first < 0 || n_frames < 1) { std::cerr << "bad sizes\n"; return 2; }
@@ -66,6 +71,7 @@ int main(int argc, char** argv) {
     rt_context* ctx[2] = {nullptr, nullptr};
     hipStream_t stream[2];
     float* fb[2];
+    float* guides[2] = {nullptr, nullptr};                  // recon: two planes of float4 per pixel
     uint8_t* rgb_dev[2];
     std::vector<uint8_t> rgb_host[2];
     flat_scene flat(world);
@@ -77,6 +83,7 @@ int main(int argc, char** argv) {
         RT_CHECK(ctx[s], rt_upload_scene(ctx[s], &desc));
         HIP_OK(hipMalloc(reinterpret_cast<void**>(&fb[s]), (size_t)W * H * 4 * sizeof(float)));
         HIP_OK(hipMalloc(reinterpret_cast<void**>(&rgb_dev[s]), (size_t)W * H * 3));
+        if (recon) HIP_OK(hipMalloc(reinterpret_cast<void**>(&guides[s]), (size_t)W * H * 8 * sizeof(float)));
         rgb_host[s].resize((size_t)W * H * 3);
     }
 
@@ -90,7 +97,7 @@ int main(int argc, char** argv) {
         st.struct_size = sizeof(st);
         RT_CHECK(ctx[s], rt_get_stats(ctx[s], &st));
         rays += st.rays; kernel_ms += st.kernel_ms;
-        const std::string path = out_dir + "/ppm_images/image_" + std::to_string(frame) + "_low.ppm";
+        const std::string path = out_dir + "/ppm_images/image_" + std::to_string(frame) + (recon ? "_recon.ppm" : "_low.ppm");
         // output_image (cuda/main.cu:358-383) on bytes that are already write_color's
         if (rt_write_ppm(path.c_str(), rgb_host[s].data(), W, H, text ? 0 : 1) != RT_OK) { std::cerr << rt_image_last_error() << "\n"; return 1; }
         return 0;
@@ -105,6 +112,10 @@ int main(int argc, char** argv) {
         p.struct_size = sizeof(p);
         p.width = W; p.height = H; p.spp = spp; p.max_depth = ray_bounce_limit; p.seed = seed + (uint64_t)frame;
         RT_CHECK(ctx[s], rt_render(ctx[s], &p, fb[s]));
+        if (recon) {
+            RT_CHECK(ctx[s], rt_render_guides(ctx[s], W, H, guides[s]));
+            RT_CHECK(ctx[s], rt_reconstruct(ctx[s], fb[s], guides[s], W, H, nullptr, fb[s]));      // in place, default parameters
+        }
         RT_CHECK(ctx[s], rt_quantize(ctx[s], fb[s], (int64_t)W * H, spp, rgb_dev[s]));
         HIP_OK(hipMemcpyAsync(rgb_host[s].data(), rgb_dev[s], rgb_host[s].size(), hipMemcpyDeviceToHost, stream[s]));
         if (pending_frame >= 0 && finish(pending_frame, pending_slot)) return 1;
@@ -115,7 +126,7 @@ int main(int argc, char** argv) {
     std::cerr << n_frames << " frames, " << rays << " rays, " << kernel_ms << " ms of kernels, " << wall_ms
               << " ms from the first launch to the last file\n";
     for (int s = 0; s < 2; s++) {
-        (void)hipFree(fb[s]); (void)hipFree(rgb_dev[s]);
+        (void)hipFree(fb[s]); (void)hipFree(rgb_dev[s]); (void)hipFree(guides[s]);
         rt_destroy(ctx[s]);
         (void)hipStreamDestroy(stream[s]);
     }

@@ -74,4 +74,27 @@ def test_cpp_sequence_driver_writes_the_python_drivers_files(tmp_path):
             got, want = open(cpp_dir / name, "rb").read(), open(py_dir / name, "rb").read()
             assert got == want, (fmt, frame)
         assert sorted(os.listdir(cpp_dir / "ppm_images")) == sorted(os.listdir(py_dir / "ppm_images"))
+    # with the reconstruction stage between render and write_color: the bytes the Python binding's calls give
+    import torch
+    cpp_dir = tmp_path / "cpp_recon"
+    subprocess.run([exe, str(scene_txt), str(cpp_dir), str(W), str(H), str(spp), str(first), "2", "p6", "recon"],
+                   capture_output=True, check=True, timeout=120)
+    cam = S.rtiow_camera(float(np.float32(W / H)))
+    fb = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+    guides = torch.zeros((2, H, W, 4), dtype=torch.float32, device="cuda")
+    rgb = torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    for frame in range(first + 2):
+        S.update_scene(cam, frame)
+        if frame < first:
+            continue
+        ctx.set_camera(**cam.desc())
+        ctx.render(api.Context.params(W, H, spp, 25, 1 + frame), fb.data_ptr())
+        ctx.render_guides(W, H, guides.data_ptr())
+        ctx.reconstruct(fb.data_ptr(), guides.data_ptr(), W, H, fb.data_ptr())
+        ctx.quantize(fb.data_ptr(), W * H, spp, rgb.data_ptr())
+        ctx.stats()
+        got = open(cpp_dir / "ppm_images" / f"image_{frame}_recon.ppm", "rb").read()
+        img = rgb.cpu().numpy()
+        assert got == f"P6\n{W} {H}\n255\n".encode("ascii") + np.ascontiguousarray(img[::-1]).tobytes(), frame
     ctx.close()
