@@ -202,7 +202,7 @@ def reconstruction_stage(device, stream_ptr):
                  "psnr_bilinear_db": psnr(bil, up_spp), "psnr_upscaled_db": psnr(up, up_spp)}
     ctx.close()
     g, r = min(g_ms), min(r_ms)
-    algo = W * H * (32 + 16 + passes * (36 + 16))       # demodulate (frame + albedo in, colour out) + per pass: colour, normal + distance, object in, colour out
+    algo = W * H * (48 + 16 + (passes - 1) * (36 + 16))       # first pass: frame, normal + distance, albedo + object in, colour out; then per pass: colour, normal + distance, object in, colour out
     return {"workload": f"{W}x{H}, frame 1 of the camera path: {low_spp}-sample frame reconstructed towards the {high_spp}-sample frame",
             "low_frame_ms": low_ms, "guides_ms": g, "reconstruct_ms": r, "passes": passes,
             "psnr_low_db": psnr(low, low_spp), "psnr_reconstructed_db": psnr(out, low_spp),

@@ -85,43 +85,55 @@ __global__ __launch_bounds__(kThreads) void atrous_kernel(const float4* __restri
     cout[at] = r;
 }
 
-// The same pass for taps that stand close (steps 1, 2 and 4): the tile's neighbourhood, (32 + 4 step) x (8 + 4 step)
-// pixels, is staged once into LDS (eight planes: colour, normal, distance, object; 14 to 37 KB) with coalesced
-// loads, and the 25 taps of every pixel are LDS reads; through the caches each pixel was fetched 25 times over.
-// Pixels beyond the image carry an object number no pixel has, so they fail the first test like any tap on
-// another object.  Same arithmetic in the same order as atrous_kernel: the two give the same bits.
+// The same pass with its taps read from LDS: the tile's neighbourhood, (TW + 4 step) x (TH + 4 step) pixels, is staged
+// once (eight planes: colour, normal, distance, object) with coalesced loads, and the 25 taps of every pixel are LDS
+// reads; through the caches each pixel was fetched 25 times over.  Steps 1, 2 and 4 take 32x8 tiles (14 to 37 KB);
+// step 8 a 64x16 tile of 1024 threads, one workgroup per CU (147 KB); wider steps stay on the caches.  Pixels beyond
+// the image carry an object number no pixel has, so they fail the first test like any tap on another object.
+// FIRST: the input is the frame as rt_render leaves it, and staging divides it by sample count and albedo (the
+// demodulation pass is folded into the first a-trous pass).  Same arithmetic in the same order as demodulate_kernel
+// and atrous_kernel: the same bits.
 constexpr int kNoPixel = (int)0x80000000;
-template <bool LAST>
-__global__ __launch_bounds__(kThreads) void atrous_lds_kernel(const float4* __restrict__ cin, const float4* __restrict__ g0,
-                                                              const float4* __restrict__ g1, int width, int height, int step,
-                                                              float sigma_color, float pass_scale, float sigma_normal,
-                                                              float inv_sigma_depth, float albedo_floor, int band_rows, int tiles_x,
-                                                              float4* __restrict__ cout) {
+template <bool FIRST, bool LAST, int TW, int TH>
+__global__ __launch_bounds__(TW * TH) void atrous_lds_kernel(const float4* __restrict__ cin, const float4* __restrict__ g0,
+                                                             const float4* __restrict__ g1, int width, int height, int step,
+                                                             float sigma_color, float pass_scale, float sigma_normal,
+                                                             float inv_sigma_depth, float albedo_floor, int band_rows, int tiles_x,
+                                                             float4* __restrict__ cout) {
     extern __shared__ float s_tile[];
+    constexpr int kWg = TW * TH;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int ty = xcd * band_rows + slot / tiles_x, tx = slot % tiles_x;
     if (slot / tiles_x >= band_rows) return;
-    const int halo = 2 * step, rw = kTileW + 2 * halo, rh = kTileH + 2 * halo, rn = rw * rh;
+    const int halo = 2 * step, rw = TW + 2 * halo, rh = TH + 2 * halo, rn = rw * rh;
     float* pc0 = s_tile; float* pc1 = pc0 + rn; float* pc2 = pc1 + rn;
     float* pn0 = pc2 + rn; float* pn1 = pn0 + rn; float* pn2 = pn1 + rn;
     float* pt = pn2 + rn;
     int* pid = reinterpret_cast<int*>(pt + rn);
-    const int x0 = tx * kTileW - halo, y0 = ty * kTileH - halo;
-    for (int i = threadIdx.x; i < rn; i += kThreads) {
+    const int x0 = tx * TW - halo, y0 = ty * TH - halo;
+    for (int i = threadIdx.x; i < rn; i += kWg) {
         const int qx = x0 + i % rw, qy = y0 + i / rw;
         if (qx >= 0 && qx < width && qy >= 0 && qy < height) {
             const long long q = (long long)qy * width + qx;
             const float4 c = cin[q], g = g0[q];
-            pc0[i] = c.x; pc1[i] = c.y; pc2[i] = c.z;
+            if (FIRST) {
+                const float4 a = g1[q];
+                const float inv = 1.0f / fmaxf(c.w, 1.0f);
+                pc0[i] = c.x * inv / fmaxf(a.x, albedo_floor); pc1[i] = c.y * inv / fmaxf(a.y, albedo_floor);
+                pc2[i] = c.z * inv / fmaxf(a.z, albedo_floor);
+                pid[i] = __float_as_int(a.w);
+            } else {
+                pc0[i] = c.x; pc1[i] = c.y; pc2[i] = c.z;
+                pid[i] = __float_as_int(g1[q].w);
+            }
             pn0[i] = g.x; pn1[i] = g.y; pn2[i] = g.z; pt[i] = g.w;
-            pid[i] = __float_as_int(g1[q].w);
         } else {
             pid[i] = kNoPixel;
         }
     }
     __syncthreads();
-    const int lx = threadIdx.x % kTileW, ly = threadIdx.x / kTileW;
-    const int x = tx * kTileW + lx, y = ty * kTileH + ly;
+    const int lx = threadIdx.x % TW, ly = threadIdx.x / TW;
+    const int x = tx * TW + lx, y = ty * TH + ly;
     if (x >= width || y >= height) return;
     const long long at = (long long)y * width + x;
     const int ci = (ly + halo) * rw + lx + halo;
@@ -223,6 +235,25 @@ hipError_t launch_upscale(const DReconstruct& rp, int low_width, int low_height,
     return hipGetLastError();
 }
 
+// one pass staged in LDS, with the tile shape of its step
+template <bool FIRST, bool LAST, int TW, int TH>
+static hipError_t launch_lds_pass(const DReconstruct& rp, int step, float scale, const float4* src, const float4* g0, const float4* g1,
+                                  float4* dst, hipStream_t stream) {
+    const int tiles_x = (rp.width + TW - 1) / TW, tiles_y = (rp.height + TH - 1) / TH;
+    const int band_rows = (tiles_y + 7) / 8;
+    const size_t lds = (size_t)(TW + 4 * step) * (TH + 4 * step) * 8 * sizeof(float);
+    auto kernel = atrous_lds_kernel<FIRST, LAST, TW, TH>;
+    if (lds > 64 * 1024) {                         // beyond the default limit of a workgroup: ask for it (160 KB per CU)
+        static bool asked = false;                 // (per instantiation; the attribute belongs to the function, on every device alike)
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        asked = true; (void)asked;
+    }
+    hipLaunchKernelGGL(kernel, dim3((unsigned)(8 * band_rows * tiles_x)), dim3(TW * TH), lds, stream, src, g0, g1, rp.width, rp.height, step,
+                       rp.sigma_color, scale, rp.sigma_normal, 1.0f / rp.sigma_depth, rp.albedo_floor, band_rows, tiles_x, dst);
+    return hipGetLastError();
+}
+
 hipError_t launch_reconstruct(const DReconstruct& rp, const float4* rgba, const float4* guides, float4* tmp, float4* out,
                               hipStream_t stream) {
     const long long n = (long long)rp.width * rp.height;
@@ -231,31 +262,43 @@ hipError_t launch_reconstruct(const DReconstruct& rp, const float4* rgba, const 
     const float4* g1 = guides + n;
     float4* a = tmp;
     float4* b = tmp + n;
-    hipLaunchKernelGGL(demodulate_kernel, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, stream, rgba, g1, n,
-                       rp.albedo_floor, a);
+    // the first pass (step 1) stages its tile in LDS and demodulates while it does; without LDS the demodulated frame
+    // is written out first
+    // (a single pass in place would read pixels other workgroups have already overwritten: that one goes through the
+    // scratch image like the unfused path)
+    const bool fused = !rp.no_lds && !(rp.iterations == 1 && out == rgba);
+    if (!fused)
+        hipLaunchKernelGGL(demodulate_kernel, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, stream, rgba, g1, n,
+                           rp.albedo_floor, a);
     const int tiles_x = (rp.width + kTileW - 1) / kTileW, tiles_y = (rp.height + kTileH - 1) / kTileH;
     const int band_rows = (tiles_y + 7) / 8;
     const dim3 grid((unsigned)(8 * band_rows * tiles_x)), block(kThreads);
     float scale = 1.0f;
     for (int it = 0; it < rp.iterations; it++, scale *= 4.0f) {
         const bool last = it == rp.iterations - 1;
+        const float4* src = (it == 0 && fused) ? rgba : a;
         float4* dst = last ? out : b;
         const int step = 1 << it;
-        if (step <= 4 && !rp.no_lds) {
-            const size_t lds = (size_t)(kTileW + 4 * step) * (kTileH + 4 * step) * 8 * sizeof(float);
-            if (last)
-                hipLaunchKernelGGL(atrous_lds_kernel<true>, grid, block, lds, stream, a, g0, g1, rp.width, rp.height, step, rp.sigma_color, scale,
-                                   rp.sigma_normal, 1.0f / rp.sigma_depth, rp.albedo_floor, band_rows, tiles_x, dst);
-            else
-                hipLaunchKernelGGL(atrous_lds_kernel<false>, grid, block, lds, stream, a, g0, g1, rp.width, rp.height, step, rp.sigma_color, scale,
-                                   rp.sigma_normal, 1.0f / rp.sigma_depth, rp.albedo_floor, band_rows, tiles_x, dst);
-        } else if (last)
-            hipLaunchKernelGGL(atrous_kernel<true>, grid, block, 0, stream, a, g0, g1, rp.width, rp.height, 1 << it, rp.sigma_color, scale,
+        hipError_t e = hipSuccess;
+        if (it == 0 && fused) {
+            e = last ? launch_lds_pass<true, true, kTileW, kTileH>(rp, step, scale, src, g0, g1, dst, stream)
+                     : launch_lds_pass<true, false, kTileW, kTileH>(rp, step, scale, src, g0, g1, dst, stream);
+        } else if (step <= 4 && !rp.no_lds) {
+            e = last ? launch_lds_pass<false, true, kTileW, kTileH>(rp, step, scale, src, g0, g1, dst, stream)
+                     : launch_lds_pass<false, false, kTileW, kTileH>(rp, step, scale, src, g0, g1, dst, stream);
+        } else if (step == 8 && !rp.no_lds) {
+            e = last ? launch_lds_pass<false, true, 64, 16>(rp, step, scale, src, g0, g1, dst, stream)
+                     : launch_lds_pass<false, false, 64, 16>(rp, step, scale, src, g0, g1, dst, stream);
+        } else if (last) {
+            hipLaunchKernelGGL(atrous_kernel<true>, grid, block, 0, stream, src, g0, g1, rp.width, rp.height, step, rp.sigma_color, scale,
                                rp.sigma_normal, 1.0f / rp.sigma_depth, rp.albedo_floor, band_rows, tiles_x, dst);
-        else
-            hipLaunchKernelGGL(atrous_kernel<false>, grid, block, 0, stream, a, g0, g1, rp.width, rp.height, 1 << it, rp.sigma_color, scale,
+        } else {
+            hipLaunchKernelGGL(atrous_kernel<false>, grid, block, 0, stream, src, g0, g1, rp.width, rp.height, step, rp.sigma_color, scale,
                                rp.sigma_normal, 1.0f / rp.sigma_depth, rp.albedo_floor, band_rows, tiles_x, dst);
-        float4* t = a; a = b; b = t;
+        }
+        if (e != hipSuccess) return e;
+        // the pass read `src` and wrote `dst`: the next one reads what was written, and writes the other scratch image
+        if (!last) { float4* t = a; a = b; b = t; }
     }
     return hipGetLastError();
 }

@@ -93,6 +93,10 @@ def test_reconstruction_matches_the_restatement_and_raises_psnr(api, oracle, rti
         ctx.reconstruct(src.data_ptr(), g.data_ptr(), W, H, src.data_ptr())
         ctx.stats()
         assert np.array_equal(src.cpu().numpy(), got)
+        one, src1 = _reconstruct(api, ctx, low, g, W, H, iterations=1)        # (a single pass in place takes another route)
+        ctx.reconstruct(src1.data_ptr(), g.data_ptr(), W, H, src1.data_ptr(), iterations=1)
+        ctx.stats()
+        assert np.array_equal(src1.cpu().numpy(), one)
     # measured on this view: 16.5 -> 25.9 dB at 1 sample, 24.2 -> 29.3 at 4, 30.6 -> 33.0 at 16
     assert gains[1][1] >= gains[1][0] + 7.0 and gains[4][1] >= gains[4][0] + 3.5 and gains[16][1] >= gains[16][0] + 1.5, gains
     # other parameters go through the same arithmetic

@@ -42,7 +42,7 @@ for spp in (4, 16):
         torch.cuda.synchronize()
     t_direct = ev[0].elapsed_time(ev[1])
     passes = 4
-    algo = W * H * (32 + 16 + passes * (36 + 16))          # demodulate + passes, bytes in and out once each
+    algo = W * H * (48 + 16 + (passes - 1) * (36 + 16))          # first pass 48 B in + 16 out (demodulation folded in), then 36 in + 16 out per pass
     print(f"{spp:3d} spp frame {t_low:7.3f} ms | guides {t_g:6.3f} ms | reconstruct ({passes} passes) {t_r:6.3f} ms = "
           f"{algo / t_r / 1e6:7.1f} GB/s of algorithmic bytes (every pass through the caches: {t_direct:6.3f} ms) | PSNR against 256 spp: {psnr(low, high, spp, 256):.2f} -> "
           f"{psnr(out, high, spp, 256):.2f} dB", flush=True)
