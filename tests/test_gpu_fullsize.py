@@ -172,3 +172,44 @@ def test_million_sphere_frame_does_not_depend_on_the_builder(api):
     for f in ("id", "t", "front_face"):
         assert np.array_equal(hits[0][f], hits[2][f]) and np.array_equal(hits[1][f], hits[2][f]), f
     assert (hits[2]["id"] >= 0).mean() > 0.5
+
+
+def test_camera_path_sequence_of_240_frames_at_256_samples(api, rtiow_flat):
+    """configs[4] at its own size: the 240 frames of the camera path (cuda/main.cu:220-279, :557-591) at 1920x1080, 256
+    samples per pixel, through the sequence driver with two contexts in flight (no files written).  Every frame is
+    rendered, in order, with the seed and camera of its number; frames picked from either side of the path's change of
+    motion at frame 200 trace exactly the rays the same frames trace when rendered alone (a frame is a pure function
+    of scene, camera and parameters, whichever context and stream it runs on), and the rays per frame stay in the band
+    of this view.  About 11 s."""
+    import torch
+    from raytrace_amd import scene as S, sequence
+    Wc, Hc, spp, n = 1920, 1080, 256, 240
+    ctxs = []
+    for _ in range(2):
+        c = api.Context(0)
+        c.upload_scene(rtiow_flat)
+        ctxs.append(c)
+    stream = torch.cuda.Stream()
+    ctxs[1].set_stream(stream.cuda_stream)
+    kept = {}
+    picked = (0, 57, 199, 200, 239)
+    done = sequence.render_sequence(ctxs[0], S.rtiow_camera(float(np.float32(Wc / Hc))), n, Wc, Hc, spp, None, max_depth=25, seed=1,
+                                    overlap_ctx=ctxs[1])
+    assert [d[0] for d in done] == list(range(n))
+    rays = np.array([d[1] for d in done], dtype=np.float64)
+    assert (rays > 2.2 * Wc * Hc * spp).all() and (rays < 3.2 * Wc * Hc * spp).all()
+    # the picked frames alone: same ray count as in the sequence (a frame is a pure function of scene, camera, parameters)
+    cam = S.rtiow_camera(float(np.float32(Wc / Hc)))
+    fb = torch.zeros((Hc, Wc, 4), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    for frame in range(n):
+        S.update_scene(cam, frame)
+        if frame in picked:
+            ctxs[0].set_camera(**cam.desc())
+            ctxs[0].render(api.Context.params(Wc, Hc, spp, 25, 1 + frame), fb.data_ptr())
+            st = ctxs[0].stats()
+            assert st["rays"] == done[frame][1], frame
+            kept[frame] = bool(torch.isfinite(fb).all()) and float(fb[..., 3].min()) == spp
+    assert all(kept.values()) and len(kept) == len(picked)
+    for c in ctxs:
+        c.close()
