@@ -244,10 +244,8 @@ static hipError_t launch_lds_pass(const DReconstruct& rp, int step, float scale,
     const size_t lds = (size_t)(TW + 4 * step) * (TH + 4 * step) * 8 * sizeof(float);
     auto kernel = atrous_lds_kernel<FIRST, LAST, TW, TH>;
     if (lds > 64 * 1024) {                         // beyond the default limit of a workgroup: ask for it (160 KB per CU)
-        static bool asked = false;                 // (per instantiation; the attribute belongs to the function, on every device alike)
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        asked = true; (void)asked;
     }
     hipLaunchKernelGGL(kernel, dim3((unsigned)(8 * band_rows * tiles_x)), dim3(TW * TH), lds, stream, src, g0, g1, rp.width, rp.height, step,
                        rp.sigma_color, scale, rp.sigma_normal, 1.0f / rp.sigma_depth, rp.albedo_floor, band_rows, tiles_x, dst);
