@@ -15,7 +15,7 @@
  *   init_render + render<<<>>>   cuda/main.cu:281-355,582  rt_render / rt_render_host
  *   pixel/sample loop, ray_color main.cc:10-35,111-126     rt_render / rt_render_host
  *   world.hit (closest hit)      main.cc:18,
- *                                sceneobject_list.h:26-39  rt_trace_primary (+ rt_trace_primary_noalloc)
+ *                                sceneobject_list.h:26-39  rt_trace_primary (+ _with, _noalloc)
  *   write_color / output_image   color.h:9-26,
  *                                cuda/main.cu:358-383      rt_quantize
  *   low / high frame pairs       cuda/main.cu:557-576,
@@ -222,6 +222,13 @@ int rt_render_host(rt_context* ctx, const rt_render_params* params, float* rgba_
  * (rt_stats.bvh_coarse_nodes == 0), else through the 64-byte ones.  The device copies of rays and hits live
  * in a buffer the context keeps, and grows when n exceeds every earlier n. */
 int rt_trace_primary(rt_context* ctx, const float* rays_host, int32_t n, float t_min, rt_hit* hits_host);
+
+/* rt_trace_primary with the choice of walk a frame has (same call site in the reference: world.hit, main.cc:18):
+ * flags 0 = the walk a frame of this scene uses (tree and spheres in LDS where they fit, else the 32-byte nodes out of
+ * device memory), RT_FLAG_NO_LDS_SCENE = never the LDS walk (what rt_trace_primary does), RT_FLAG_FLOAT_NODES = the
+ * 64-byte single-precision nodes.  Same answers whichever walk; for holding each walk against a checker with explicit
+ * rays.  Other flag bits are RT_ERR_INVALID. */
+int rt_trace_primary_with(rt_context* ctx, const float* rays_host, int32_t n, float t_min, uint32_t flags, rt_hit* hits_host);
 
 /* rt_trace_primary for callers that cannot allocate device memory: tight serving loops, harnesses that
  * forbid hipMalloc.  No counterpart in the reference (its world.hit runs on host memory it already owns).

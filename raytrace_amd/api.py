@@ -19,7 +19,7 @@ RT_FLAG_MEAN, RT_FLAG_NO_REFINE, RT_FLAG_COUNTERS, RT_FLAG_PHASE_CLOCKS, RT_FLAG
 RT_FLAG_ALL_FEATURES = 256
 
 EXPORTS = ["rt_create", "rt_destroy", "rt_set_stream", "rt_upload_scene", "rt_set_camera",
-           "rt_shard_rows", "rt_render", "rt_render_host", "rt_trace_primary", "rt_trace_primary_noalloc", "rt_quantize",
+           "rt_shard_rows", "rt_render", "rt_render_host", "rt_trace_primary", "rt_trace_primary_with", "rt_trace_primary_noalloc", "rt_quantize",
            "rt_resolve_sums", "rt_render_guides", "rt_reconstruct", "rt_upscale", "rt_get_stats", "rt_last_error", "rt_version",
            "rt_decode_jpeg", "rt_load_jpeg_file", "rt_free_image", "rt_image_last_error", "rt_write_ppm"]
 
@@ -117,6 +117,7 @@ def lib():
         L.rt_render.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.c_void_p]
         L.rt_render_host.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.c_void_p]
         L.rt_trace_primary.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_void_p]
+        L.rt_trace_primary_with.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_uint32, C.c_void_p]
         L.rt_trace_primary_noalloc.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_void_p]
         L.rt_quantize.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]
         L.rt_resolve_sums.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]
@@ -282,11 +283,16 @@ class Context:
         self._check(lib().rt_render_host(self._h, C.byref(params), out.ctypes.data))
         return out
 
-    def trace_primary(self, rays, t_min=0.001, noalloc=False):
+    def trace_primary(self, rays, t_min=0.001, noalloc=False, walk=None):
         """noalloc: through rt_trace_primary_noalloc (fixed device staging, at most
-        TRACE_NOALLOC_MAX_RAYS rays, no device allocation in the call)."""
+        TRACE_NOALLOC_MAX_RAYS rays, no device allocation in the call).
+        walk: through rt_trace_primary_with: 0 = the walk a frame of the scene uses (LDS where it fits), or
+        RT_FLAG_NO_LDS_SCENE / RT_FLAG_FLOAT_NODES."""
         rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
         hits = np.zeros(rays.shape[0], HIT_DTYPE)
+        if walk is not None:
+            self._check(lib().rt_trace_primary_with(self._h, rays.ctypes.data, rays.shape[0], C.c_float(t_min), int(walk), hits.ctypes.data))
+            return hits
         fn = lib().rt_trace_primary_noalloc if noalloc else lib().rt_trace_primary
         self._check(fn(self._h, rays.ctypes.data, rays.shape[0], C.c_float(t_min), hits.ctypes.data))
         return hits

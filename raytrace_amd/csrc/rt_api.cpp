@@ -704,7 +704,19 @@ int rt_render_host(rt_context* ctx, const rt_render_params* params, float* rgba_
     return RT_OK;
 }
 
+static int trace_primary(rt_context* ctx, const float* rays_host, int32_t n, float t_min, uint32_t flags, rt_hit* hits_host);
+
 int rt_trace_primary(rt_context* ctx, const float* rays_host, int32_t n, float t_min, rt_hit* hits_host) {
+    return trace_primary(ctx, rays_host, n, t_min, 0u, hits_host);
+}
+
+int rt_trace_primary_with(rt_context* ctx, const float* rays_host, int32_t n, float t_min, uint32_t flags, rt_hit* hits_host) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (flags & ~(uint32_t)(RT_FLAG_NO_LDS_SCENE | RT_FLAG_FLOAT_NODES)) return fail(ctx, RT_ERR_INVALID, "rt_trace_primary_with: unknown flag");
+    return trace_primary(ctx, rays_host, n, t_min, flags | 512u, hits_host);      // 512: the LDS walk where the scene fits
+}
+
+static int trace_primary(rt_context* ctx, const float* rays_host, int32_t n, float t_min, uint32_t flags, rt_hit* hits_host) {
     if (!ctx) return RT_ERR_INVALID;
     if (!ctx->has_scene) return fail(ctx, RT_ERR_NO_SCENE, "no scene uploaded");
     if (n < 0 || (n > 0 && (!rays_host || !hits_host))) return fail(ctx, RT_ERR_INVALID, "bad ray arrays");
@@ -723,7 +735,7 @@ int rt_trace_primary(rt_context* ctx, const float* rays_host, int32_t n, float t
     float* d_rays = reinterpret_cast<float*>(ctx->trace_buf);
     rt::Hit* d_hits = reinterpret_cast<rt::Hit*>(ctx->trace_buf + ctx->trace_rays * 6 * sizeof(float));
     hipError_t e = hipMemcpyAsync(d_rays, rays_host, (size_t)n * 6 * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = rt::launch_trace(ctx->scene, d_rays, n, t_min == 0.0f ? 0.001f : t_min, 0u, d_hits, ctx->stream);
+    if (e == hipSuccess) e = rt::launch_trace(ctx->scene, d_rays, n, t_min == 0.0f ? 0.001f : t_min, flags, d_hits, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(hits_host, d_hits, (size_t)n * sizeof(rt::Hit), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) return fail(ctx, RT_ERR_HIP, std::string("rt_trace_primary: ") + hipGetErrorString(e));

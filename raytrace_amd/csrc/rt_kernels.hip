@@ -1429,6 +1429,42 @@ __device__ __forceinline__ Cand closest_hit(const DScene& sc, V3 o, V3 d, float 
 }
 
 
+// The same query through the walk a frame of a small scene uses: tree and spheres staged into LDS (plane-addressed
+// 80-byte nodes, 16-bit stack entries), so that explicit rays can be held against the checker on that walk too.
+// Dynamic LDS: [stack: stack_depth x kBlock ints holding 16-bit entries][nodes][spheres][list positions].
+__global__ __launch_bounds__(kBlock) void trace_lds_kernel(DScene sc, const float* __restrict__ rays, int n, float t_min,
+                                                           uint32_t flags, int stack_depth, Hit* __restrict__ out) {
+    extern __shared__ __align__(16) int s_dyn[];
+    int* stack = reinterpret_cast<int*>(reinterpret_cast<short*>(s_dyn) + threadIdx.x);
+    *reinterpret_cast<short*>(stack) = (short)kTravDone16;
+    const GeoLds geo = stage_geometry<true, 0>(sc, s_dyn + stack_depth * kBlock);
+    __syncthreads();
+    int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    V3 o = mk(rays[6 * i], rays[6 * i + 1], rays[6 * i + 2]);
+    V3 d = mk(rays[6 * i + 3], rays[6 * i + 4], rays[6 * i + 5]);
+    Counters cn = {0, 0, 0, 0, 0, 0, 0, 0};
+    Cand c = no_hit();
+    const RayN rn = normalise(d, t_min);
+    hit_always<false, kFeatAll>(sc, nullptr, o, d, rn, t_min, no_origin(), c, cn);
+    if (sc.root != kNoBvh) {
+        int cur = geo.root_ref(sc.root), sp = 0;
+        hit_bvh<false, 0>(geo, o, rn, no_origin(), stack, 2 * stack_depth, 0, 0, cur, sp, c, cn);
+    }
+    Hit h;
+    if (c.kind < 0) {
+        h.id = -1; h.t = 0.0f; h.front = 0; h.u = 0.0f; h.v = 0.0f;
+        for (int a = 0; a < 3; a++) { h.p[a] = 0.0f; h.n[a] = 0.0f; }
+    } else {
+        const double4 s64 = c.kind == 0 ? sc.sph64[c.idx] : make_double4(0.0, 0.0, 0.0, 1.0);
+        Rec r = make_record<kFeatAll>(sc, nullptr, c, o, d, rn.inv_len, (flags & 2u) == 0u, true, s64, c.kind == 0 ? sc.sph_info[c.idx].y : 0);
+        h.id = r.obj; h.t = r.t; h.front = r.front; h.u = r.u; h.v = r.v;
+        h.p[0] = r.p.x; h.p[1] = r.p.y; h.p[2] = r.p.z;
+        h.n[0] = r.n.x; h.n[1] = r.n.y; h.n[2] = r.n.z;
+    }
+    out[i] = h;
+}
+
 template <int QUANT>
 __global__ __launch_bounds__(kBlock) void trace_kernel(DScene sc, const float* __restrict__ rays, int n, float t_min,
                                                        uint32_t flags, Hit* __restrict__ out) {
@@ -1642,7 +1678,16 @@ hipError_t launch_render(const DScene& sc, const DCamera& cam, const DRender& rp
 hipError_t launch_trace(const DScene& sc, const float* rays, int n, float t_min, uint32_t flags, Hit* out,
                         hipStream_t stream) {
     if (n <= 0) return hipSuccess;
-    // the walk a frame of this scene would use when the tree does not fit in LDS
+    // flags & 512: the walk a frame of this scene uses: tree and spheres in LDS where they fit (launch_render's rule)
+    if ((flags & 512u) != 0u && (flags & 32u) == 0u && sc.use_bvh && sc.n_sph > 0 && sc.ids_fit_16 && sc.n_sph_padded + 8 < 4096) {
+        const int short_depth = (sc.bvh_depth + 2 + 1) / 2;
+        const size_t lds = (size_t)short_depth * kBlock * sizeof(int) + (size_t)sc.n_nodes * kLdsNodeBytes + (size_t)sc.n_sph_padded * 20;
+        if (lds <= 40 * 1024) {
+            hipLaunchKernelGGL(trace_lds_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), lds, stream, sc, rays, n, t_min, flags, short_depth, out);
+            return hipGetLastError();
+        }
+    }
+    // else the walk a frame of this scene uses when the tree does not fit in LDS
     if (sc.use_bvh && sc.qnodes != nullptr && (flags & 128u) == 0u)
         hipLaunchKernelGGL(trace_kernel<1>, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, sc, rays, n, t_min, flags, out);
     else

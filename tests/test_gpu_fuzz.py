@@ -224,6 +224,9 @@ def test_random_sphere_field(seed, oracle):
         ctx.upload_scene(flat, accel=accel)
         ctx.set_camera(**cam)
         hits = ctx.trace_primary(rays)
+        # the walk a frame of this scene takes (the tree in LDS where it fits) and the single-precision nodes: the same bits
+        assert ctx.trace_primary(rays, walk=0).tobytes() == hits.tobytes(), accel
+        assert ctx.trace_primary(rays, walk=api.RT_FLAG_NO_LDS_SCENE | api.RT_FLAG_FLOAT_NODES).tobytes() == hits.tobytes(), accel
         bad = hits["id"] != want["id"]
         # a root that close to t_min is the other kind of ray single precision cannot decide like
         # double: the sphere records are rounded to float, which moves a surface by 1e-7 of its

@@ -26,10 +26,17 @@ def ctx(request, api, rtiow_flat):
     c.close()
 
 
-def test_primary_ray_hits_match_main_cc(ctx):
-    """north-star gate: hit object ids bit-exact, t and normals within 1e-5 relative."""
+@pytest.mark.parametrize("walk", ["default", "frame", "hbm", "float nodes"])
+def test_primary_ray_hits_match_main_cc(ctx, api, walk):
+    """north-star gate: hit object ids bit-exact, t and normals within 1e-5 relative, through every walk a
+    frame can use: rt_trace_primary (the 32-byte nodes out of device memory, or the scan), and
+    rt_trace_primary_with for the walk a frame of this scene takes (tree and spheres in LDS), the walk out of
+    device memory and the 64-byte single-precision nodes."""
     g = load_golden("primary_rays.npz")
-    hits = ctx.trace_primary(g["rays"], float(g["t_min"]))
+    which = {"default": None, "frame": 0, "hbm": api.RT_FLAG_NO_LDS_SCENE, "float nodes": api.RT_FLAG_NO_LDS_SCENE | api.RT_FLAG_FLOAT_NODES}[walk]
+    hits = ctx.trace_primary(g["rays"], float(g["t_min"]), walk=which)
+    if walk != "default":                      # the same answer bit for bit, whichever walk found it
+        assert hits.tobytes() == ctx.trace_primary(g["rays"], float(g["t_min"])).tobytes()
     # grazing rays in the fixture keep |b/r - 1| >= 1e-4 from a silhouette: decidable in float
     assert np.min(g["graze_margin"][g["kind"] == 1]) > 5e-5
     assert np.array_equal(hits["id"], g["id"])
