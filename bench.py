@@ -334,7 +334,9 @@ def _free_port():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=None,
+                    help="timed steps (default: 100 frames of c2, about 1.7 s on one GPU, so that a sampler outside the process "
+                         "sees the timed region; 10 of the other configurations)")
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", choices=["c2", "c3", "c4", "c5"], default="c2")
     ap.add_argument("--partition", choices=["tiles", "samples", "frames+samples"], default=None,
@@ -361,6 +363,8 @@ def main():
     ap.add_argument("--check", action="store_true",
                     help="rank 0 also renders every timed frame alone and compares it bit for bit with the assembled one")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 100 if args.config == "c2" else 10
 
     import numpy as np
     import torch
