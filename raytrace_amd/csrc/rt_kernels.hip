@@ -327,6 +327,9 @@ using GeoGlobalQ = GeoGlobalQT<false>;
 // all twelve and selecting; the selects were a fifth of the node step's VALU time and LDS has
 // bandwidth to spare.  Inner-node references are the nodes' LDS byte addresses in units of 16
 // bytes ((node_base + index * 80) / 16), leaves keep their negative codes.
+#ifndef RT_FUSE_DRAWS
+#define RT_FUSE_DRAWS 1                // which kernels draw a trip's scatter and camera numbers in one place (bits: see render_kernel)
+#endif
 #ifndef RT_LDS_NODE_WORDS
 #define RT_LDS_NODE_WORDS 20
 #endif
@@ -921,7 +924,8 @@ __device__ __forceinline__ V3 material_color(const DScene& sc, const DMaterial& 
 struct Key { uint32_t seed_lo, seed_hi, pixel, sample; };
 
 __device__ __forceinline__ float u01(uint32_t w) { return (float)(w >> 8) * 5.9604644775390625e-08f; }  // 2^-24
-__device__ __forceinline__ float pm1(uint32_t w) { return fmaf(2.0f, u01(w), -1.0f); }                   // random_double(-1,1)
+// random_double(-1,1) = 2 u - 1 with u = k 2^-24: k 2^-23 - 1 rounded once either way, so one multiply-add gives the same bits as two steps
+__device__ __forceinline__ float pm1(uint32_t w) { return fmaf((float)(w >> 8), 1.1920928955078125e-07f, -1.0f); }
 
 // The draws of a segment beyond its Philox block: one step of the xoshiro128 linear engine
 // (Blackman, Vigna) per rejection ATTEMPT, started from the block as state and stepped twice before
@@ -1295,6 +1299,229 @@ __global__ __launch_bounds__(kBlock, MODE == 0 ? RT_WG_PER_CU_SCAN : (LDS ? (MOD
     // on a lane with a path means "ray not started yet".
     Cand c = no_hit();
     int cur = kDone, sp = 0;
+    // RT_FUSE_DRAWS bits: 1 walks in LDS left between rounds, 2 scans, 4 the other walks in LDS, 8 walks out of HBM
+    constexpr bool FUSE = ((RT_FUSE_DRAWS & 1) && MODE == 3 && LDS) || ((RT_FUSE_DRAWS & 2) && MODE == 0) ||
+                          ((RT_FUSE_DRAWS & 4) && (MODE == 1 || MODE == 2) && LDS) || ((RT_FUSE_DRAWS & 8) && MODE != 0 && !LDS);
+    if constexpr (FUSE) {
+    // The same loop with the random draws of a trip in one place.  A query that ends on a scattering surface
+    // leaves its scatter pending (the surface point in o, the incoming unit direction in d, the normal and
+    // the material's numbers beside them); a lane that takes a new unit is `fresh`.  Both kinds then draw
+    // together: one Philox block per lane (segment 0 for a fresh lane, the path's segment for a pending
+    // one) and one rejection loop (a point in the unit disk for the lens, in the unit sphere for the
+    // scatter: the disk's is the sphere's with the third coordinate held at zero, the same arithmetic
+    // bit for bit), instead of a block and a loop for the third of the lanes that start a sample and
+    // another of each for the lanes that scatter.
+    constexpr bool EMIT = (FEAT & kFeatEmitters) != 0;
+    Cand& c_member = c;
+    int &cur_member = cur, &sp_member = sp;
+    int pend = 0;                                      // 0: nothing pending; else 1 + material type
+    bool fresh = false, sflip = false;
+    int fx = 0, fj = 0;
+    V3 sn = mk(0, 0, 0);
+    float sa = 0.0f, sb = 0.0f;
+    for (;;) {
+        if (PROF) tq = clk();
+        if (old_valid && __ballot(has && (q >> logP) != cur_buf) == 0ull) {
+            write_tile(cur_buf ^ 1);
+            old_valid = false;
+        }
+        if (cur_valid && next >= tile_units && !old_valid) {
+            old_valid = true;
+            cur_buf ^= 1; cur_valid = false;
+        }
+        if (!cur_valid && more_tiles) {
+            unsigned tile = n_tiles;
+            while (bands_tried < kBands) {
+                const unsigned b0 = (unsigned)(((unsigned long long)n_tiles * band) / kBands), b1 = (unsigned)(((unsigned long long)n_tiles * (band + 1)) / kBands);
+                unsigned t = 0u;
+                if (lane == 0) t = atomicAdd(tile_counter + band, 1u);
+                t = (unsigned)__builtin_amdgcn_readfirstlane((int)t);
+                if (b0 + t < b1) { tile = b0 + t; break; }
+                band = (band + 1) % kBands;
+                bands_tried++;
+            }
+            if (tile >= n_tiles) more_tiles = false;
+            else {
+                cur_valid = true; next = 0u;
+                if (lane < P) {
+                    const int slot = cur_buf * P + lane;
+                    accum[slot * 3 + 0] = 0ull; accum[slot * 3 + 1] = 0ull; accum[slot * 3 + 2] = 0ull;
+                    const int x = (int)(tile % (unsigned)tiles_x) * TW + (lane % TW), ly = (int)(tile / (unsigned)tiles_x) * TH + (lane / TW);
+                    const int j = (rp.tile_first + (ly / rp.tile_rows) * rp.tile_step) * rp.tile_rows + (ly % rp.tile_rows);
+                    tile_pix[slot] = make_int2((x < rp.width && ly < rp.rows && j < rp.height) ? x : -1, j);
+                    if (lane == 0) tile_row[cur_buf] = ly;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        const unsigned long long need = __ballot(!has);
+        if (need != 0ull && cur_valid && next < tile_units) {
+            const unsigned u = next + __builtin_amdgcn_mbcnt_hi((unsigned)(need >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)need, 0u));
+            if (!has && u < tile_units) {
+                q = (int)(u & (unsigned)(P - 1)) + (cur_buf << logP);
+                const int2 xj = tile_pix[q];
+                if (xj.x >= 0) {
+                    fx = xj.x; fj = xj.y;
+                    key.pixel = (uint32_t)(fj * rp.width + fx);
+                    key.sample = (uint32_t)rp.sample_begin + (uint32_t)(u >> logP);
+                    T = mk(1.0f, 1.0f, 1.0f);
+                    L = mk(0.0f, 0.0f, 0.0f);
+                    depth = 0;
+                    from = no_origin();
+                    nsamples++;
+                    has = true; fresh = true;
+                }
+            }
+            next += (unsigned)__popcll(need);
+        }
+        if (PROF) { unsigned long long t = clk(); ph[0] += t - tq; tq = t; }
+        if (__ballot(has) == 0ull) {
+            if (!cur_valid && !old_valid && !more_tiles) break;
+            continue;
+        }
+        if (has && (fresh || pend != 0)) {
+            const uint4 w = philox4x32_10<FEAT == 0 || LDS, !LDS>(key.pixel, key.sample, fresh ? 0u : (uint32_t)depth, 0u, key.seed_lo, key.seed_hi);
+            const bool lens = s_cam.lens_radius != 0.0f;
+            const bool want = fresh ? lens : (pend == 1 || (pend == 2 && sa > 0.0f));
+            // sphere: (X, Y, Z) = the point, first attempt from words z, y, x of the block (vec3.h:130-136, in_unit_sphere);
+            // disk: X = py from word z, Y = px from word w, Z = 0 (vec3.h:150-156, camera_ray)
+            // (the choice between the two by a per-lane bit mask: selects on a lane condition issue at half rate)
+            const uint32_t km = fresh ? 0xffffffffu : 0u;
+            float X = pm1(w.z), Y = pm1((w.w & km) | (w.y & ~km)), Z = __uint_as_float(__float_as_uint(pm1(w.x)) & ~km);
+            if (want && fmaf(Z, Z, fmaf(Y, Y, X * X)) >= 1.0f) {
+                Xo g; g.s0 = w.x; g.s1 = w.y; g.s2 = w.z; g.s3 = w.w;
+                xo_step(g);
+                for (int i = 0; i < 256; i++) {
+                    xo_step(g);
+                    const uint32_t ua = __float_as_uint(pm1(g.s0 + g.s3)), uc = __float_as_uint(pm1(g.s0 - g.s3));
+                    Y = pm1(g.s1 + g.s2);
+                    X = __uint_as_float((ua & km) | (uc & ~km));
+                    Z = __uint_as_float(ua & ~km);
+                    if (!(fmaf(Z, Z, fmaf(Y, Y, X * X)) >= 1.0f)) break;
+                }
+            }
+            if (fresh) {                                   // camera.h:40-45, main.cc:117-118 (camera_ray)
+                const float s = ((float)fx + u01(w.x)) * rp.inv_wm1;
+                const float t = ((float)fj + u01(w.y)) * rp.inv_hm1;
+                V3 offset = mk(0.0f, 0.0f, 0.0f);
+                if (lens) {
+                    const float rx = s_cam.lens_radius * Y, ry = s_cam.lens_radius * X;
+                    offset = madd(rx * ld3(s_cam.u), ry, ld3(s_cam.v));
+                }
+                o = ld3(s_cam.origin) + offset;
+                d = madd(madd(ld3(s_cam.llc_rel), s, ld3(s_cam.horizontal)), t, ld3(s_cam.vertical)) - offset;
+                fresh = false;
+            } else {                                       // material.h:21-32, 42-47, 58-91 (scatter)
+                const V3 rs = mk(X, Y, Z), ud = d;
+                V3 sd;
+                bool cont = true;
+                if (pend == 1) {
+                    const V3 uvec = __builtin_amdgcn_rsqf(dot(rs, rs)) * rs;
+                    V3 dir = sn + uvec;
+                    const float thr = 1e-8f;
+                    if (fabsf(dir.x) < thr && fabsf(dir.y) < thr && fabsf(dir.z) < thr) dir = sn;
+                    sd = dir;
+                } else if (pend == 2) {
+                    V3 refl = reflect(ud, sn);
+                    if (sa > 0.0f) refl = madd(refl, sa, rs);
+                    sd = refl;
+                    cont = dot(sd, sn) > 0.0f;
+                } else {
+                    const float ratio = sa, r0 = sb;
+                    const float cos_theta = fminf(dot(-ud, sn), 1.0f);
+                    const float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+                    const bool tir = ratio * sin_theta > 1.0f;
+                    const float x = 1.0f - cos_theta;
+                    const float x2 = x * x;
+                    const float refl_prob = r0 + (1.0f - r0) * (x2 * x2 * x);
+                    if (tir || refl_prob > u01(w.x)) {
+                        sd = reflect(ud, sn);
+                    } else {
+                        const V3 perp = ratio * madd(ud, cos_theta, sn);
+                        const float par = -sqrtf(fabsf(1.0f - dot(perp, perp)));
+                        sd = madd(perp, par, sn);
+                    }
+                }
+                d = sd;
+                const bool into = (dot(sd, sn) < 0.0f) == sflip;
+                from.code |= (into ? 1 : 0) << 28;
+                pend = 0;
+                if (!cont) {                               // absorbed: the path ends with what it has collected
+                    if constexpr (EMIT) {
+                        atomicAdd(&accum[q * 3 + 0], to_fixed(L.x));
+                        atomicAdd(&accum[q * 3 + 1], to_fixed(L.y));
+                        atomicAdd(&accum[q * 3 + 2], to_fixed(L.z));
+                    }
+                    has = false;
+                }
+            }
+        }
+        // (what the draws have consumed is dead from here on; saying so keeps it out of the walk's registers)
+        pend = 0; fresh = false; sflip = false; fx = 0; fj = 0; sa = 0.0f; sb = 0.0f; sn = mk(0.0f, 0.0f, 0.0f);
+        if (PROF) { unsigned long long t = clk(); ph[3] += t - tq; tq = t; }
+        if (has) {
+            const RayN rn = normalise(d, rp.t_min);
+            // without time slices a query starts and ends inside one trip: its state is local
+            Cand c_trip = no_hit();
+            int cur_trip = kDone, sp_trip = 0;
+            Cand& c = *(SLICED ? &c_member : &c_trip);
+            int& cur = *(SLICED ? &cur_member : &cur_trip);
+            int& sp = *(SLICED ? &sp_member : &sp_trip);
+            if (cur == kDone) {
+                c = no_hit();
+                hit_always<COUNT, FEAT>(sc, staged, o, d, rn, rp.t_min, from, c, cn);
+                nrays++;
+                depth++;
+                if constexpr (!BVH) hit_list<COUNT, LDS>(sc, staged_list, o, rn, from, c, cn);
+                else if (sc.root != kNoBvh) { hit_own_sphere(geo, o, rn, from, c); cur = geo.root_ref(sc.root); sp = 0; }
+            }
+            if (PROF) { unsigned long long t = clk(); ph[1] += t - tq; tq = t; }
+            if constexpr (BVH)
+                if (cur != kDone) hit_bvh<COUNT, MODE == 2 ? 1 : (MODE == 3 ? 2 : 0)>(geo, o, rn, from, stack, rp.stack_entries, rp.slice, rp.leaf_quorum, cur, sp, c, cn);
+            if (PROF) { unsigned long long t = clk(); ph[2] += t - tq; tq = t; }
+            if (cur == kDone) {                        // query finished: the record and the material, no draws
+                bool ended;
+                if constexpr (!EMIT) L = mk(0.0f, 0.0f, 0.0f);
+                if (c.kind < 0) {
+                    L = L + T * background(sc, rn.dh);
+                    ended = true;
+                } else {
+                    constexpr bool RECTS = (FEAT & kFeatRects) != 0, TEX = (FEAT & kFeatTextures) != 0;
+                    const int mat = c.kind == 0 ? geo.mat(c.idx) : ((!RECTS || c.kind == 1) ? sc.wide[c.idx].mat : (staged_rects(FEAT) ? staged[c.idx].mat : sc.rects[c.idx].mat));
+                    const double4 s64 = c.kind == 0 ? sc.sph64[c.idx] : make_double4(0.0, 0.0, 0.0, 1.0);
+                    DMaterial m = sc.mats[mat];
+                    if (!TEX) m.tex = -1;
+                    const Rec r = make_record<FEAT>(sc, staged, c, o, d, rn.inv_len, refine, m.tex >= 0, s64, mat);
+                    if (COUNT) cn.shade++;
+                    const int type = EMIT ? m.type : (m.type > 2 ? 0 : m.type);
+                    if (type > 2) {                        // diffuse_light, lambertian_bg
+                        if constexpr (EMIT) L = L + T * material_color(sc, m, r);
+                        ended = true;
+                    } else {
+                        const V3 att = type == 0 ? material_color(sc, m, r) : (type == 1 ? mk(m.r, m.g, m.b) : mk(1.0f, 1.0f, 1.0f));
+                        T = T * att;
+                        ended = depth >= rp.max_depth;     // main.cc:13-14: the limit ends in black
+                        o = r.p;
+                        d = rn.dh;
+                        sn = r.n;
+                        sa = type == 1 ? m.fuzz : (r.front ? m.r : m.ir);
+                        sb = r.front ? m.g : m.b;
+                        sflip = (r.front != 0) != r.hollow;
+                        from = origin_of(c.kind, c.idx, false);
+                        pend = ended ? 0 : type + 1;
+                    }
+                }
+                if (ended) {
+                    atomicAdd(&accum[q * 3 + 0], to_fixed(L.x));
+                    atomicAdd(&accum[q * 3 + 1], to_fixed(L.y));
+                    atomicAdd(&accum[q * 3 + 2], to_fixed(L.z));
+                    has = false;
+                }
+            }
+            if (PROF) { unsigned long long t = clk(); ph[4] += t - tq; tq = t; }
+        }
+    }
+    } else
     for (;;) {
         if (PROF) tq = clk();
         // the older tile's last path has ended: write its pixels

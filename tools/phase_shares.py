@@ -29,5 +29,5 @@ for name, make, cam, accel, spp in cases:
     ph = st["phase_clocks"]
     tot = float(sum(ph)) or 1.0
     print(f"{name:28s} {ms:8.2f} ms (phase build {st['kernel_ms']:8.2f})  rays {st['rays'] / 1e6:8.1f} M  hand-out+camera {ph[0] / tot:5.1%}  "
-          f"always/scan {ph[1] / tot:5.1%}  walk {ph[2] / tot:5.1%}  shading {ph[4] / tot:5.1%}", flush=True)
+          f"draws (kernels that draw in one place) {ph[3] / tot:5.1%}  always/scan {ph[1] / tot:5.1%}  walk {ph[2] / tot:5.1%}  shading {ph[4] / tot:5.1%}", flush=True)
     ctx.close()
