@@ -1,7 +1,7 @@
 """Shares of a wave's time by phase of the path loop (the phase-clock build of the all-features kernel: unit
 hand-out and camera rays / always-tested primitives and the scan / tree walk / shading), for the four bench scenes
 at reduced sample counts.  The production kernels are specialised builds; the shares are a guide, not a measurement of them.
-usage: python tools/phase_shares.py"""
+usage: python tools/phase_shares.py [--lib other/librt_amd.so]"""
 import os
 import sys
 
@@ -10,6 +10,8 @@ import numpy as np                                # noqa: E402
 import torch                                      # noqa: E402
 from raytrace_amd import api, scene as S          # noqa: E402
 
+if "--lib" in sys.argv:                           # another build of the library
+    api.LIB_PATH = os.path.abspath(sys.argv[sys.argv.index("--lib") + 1])
 A = float(np.float32(16 / 9))
 room = dict(background=S.RT_BG_SOLID, bg_color=(0, 0, 0))
 cases = [("default world @100", lambda: S.flatten(S.rtiow_scene()), S.rtiow_camera(A), api.RT_ACCEL_BVH, 100),
