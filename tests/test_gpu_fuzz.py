@@ -164,8 +164,10 @@ def test_random_scene(seed, oracle):
         assert np.sqrt(np.mean((img[..., :3] / spp - sums / spp) ** 2)) <= 0.02 * peak
 
 
-def _random_field(S, rng):
-    """Hundreds to thousands of small spheres: trees of 8 to 14 levels, in LDS or beyond it."""
+def _random_field(S, rng, plain=False):
+    """Hundreds to thousands of small spheres: trees of 8 to 14 levels, in LDS or beyond it.
+    plain: no emitter among the materials, so that the frame takes the kernels built for scenes of plainly
+    coloured spheres (the walk left between rounds of leaves, the draws of a trip in one place)."""
     n = int(rng.choice([150, 500, 1500, 4000]))
     scale = float(rng.choice([1.0, 50.0]))
     offset = rng.uniform(-3, 3, 3) * scale * float(rng.choice([0.0, 1.0]))
@@ -174,6 +176,8 @@ def _random_field(S, rng):
     w.add(S.sphere(offset + [0, -1000 * scale, 0], 1000 * scale, S.lambertian(rng.uniform(0.3, 0.7, 3))))
     mats = [S.lambertian(rng.uniform(0.1, 0.9, 3)) for _ in range(6)] + [S.metal(rng.uniform(0.5, 1, 3), 0.0), S.metal(rng.uniform(0.5, 1, 3), 0.4),
                                                                          S.dielectric(1.5), S.diffuse_light((3, 3, 3))]
+    if plain:
+        mats[-1] = mats[0]                                      # (after the draws, so that a seed's field is the same but for its lights)
     c = rng.uniform(-0.5, 0.5, (n, 3)) * [side, 0.15 * side, side] + [0, 0.12 * side, 0]
     r = rng.uniform(0.15, 0.6, n)
     for k in range(n):
@@ -198,7 +202,7 @@ _KEPT_FIELDS = [84596]
 def test_random_sphere_field(seed, oracle):
     from raytrace_amd import api, scene as S
     rng = np.random.default_rng(50000 + seed)
-    flat, cam, scale, offset, side = _random_field(S, rng)
+    flat, cam, scale, offset, side = _random_field(S, rng, plain=seed % 3 == 1)      # every third field without lights
     cd = oracle.camera(**cam)
     rays = [oracle.get_ray(cd, rng.random(), rng.random(), 5, k, 0)[0] for k in range(1000)]
     for _ in range(1000):
