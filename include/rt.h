@@ -185,7 +185,10 @@ typedef struct rt_stats {
     uint64_t rays;               /* closest-hit queries (one per world.hit call, main.cc:18) */
     uint64_t samples;            /* camera samples */
     uint64_t box_tests, sphere_tests, sphere_hits, rect_tests, wide_tests, shades; /* RT_FLAG_COUNTERS */
-    uint64_t phase_clocks[5];    /* RT_FLAG_PHASE_CLOCKS: camera, always-tested, traversal, record, scatter */
+    uint64_t phase_clocks[5];    /* RT_FLAG_PHASE_CLOCKS: [0] unit hand-out (and camera rays), [1] always-tested primitives / scan,
+                                    [2] tree walk, [3] the draws of a trip (kernels that draw in one place: camera rays and scatter),
+                                    [4] shading (records, materials; scatter too in the other kernels).  With RT_FLAG_COUNTERS [0] and [1]
+                                    hold the traversal steps of all lanes and of the waves instead */
     float kernel_ms;             /* device time of the last render kernel (HIP events on its stream) */
     int32_t lanes_per_pixel;     /* value the last render used */
     int32_t accel;               /* RT_ACCEL_LIST or RT_ACCEL_BVH actually used (either builder) */
