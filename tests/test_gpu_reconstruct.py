@@ -189,3 +189,46 @@ def test_upscale_matches_the_restatement_and_beats_interpolation(api, rtiow_flat
     with pytest.raises(api.RtError):
         ctx.upscale(low_t.data_ptr(), gl_t.data_ptr(), lw, lh, gh_t.data_ptr(), 480, 320, out.data_ptr(), sigma_depth=-1.0)
     ctx.close()
+
+
+@pytest.mark.parametrize("size", [(1, 1), (2, 2), (5, 3), (33, 9), (31, 8), (65, 17), (130, 37)])
+def test_reconstruction_of_ragged_frames(api, size):
+    """Frames smaller than a tile, one pixel wider than a tile and not a multiple of one, on made-up guides (three
+    objects, the background, normals and distances that vary): the staged passes, the passes through the caches
+    and the restatement agree, and nothing outside the frame is touched."""
+    import torch
+    from oracle import reconstruct as R
+    W, H = size
+    rng = np.random.default_rng(W * 1000 + H)
+    spp = 4
+    ids = rng.integers(-1, 3, (H, W)).astype(np.int32)
+    n = rng.normal(size=(H, W, 3)); n /= np.linalg.norm(n, axis=-1, keepdims=True)
+    g0 = np.concatenate([n, rng.uniform(1.0, 20.0, (H, W, 1))], -1).astype(np.float32)
+    g0[ids < 0] = 0.0
+    alb = rng.uniform(0.05, 1.0, (H, W, 3)).astype(np.float32)
+    alb[ids < 0] = 1.0
+    low = np.concatenate([rng.uniform(0.0, 2.0, (H, W, 3)) * spp, np.full((H, W, 1), float(spp))], -1).astype(np.float32)
+    guides = np.zeros((2, H, W, 4), np.float32)
+    guides[0] = g0
+    guides[1, ..., :3] = alb
+    guides[1, ..., 3] = ids.view(np.float32)
+    ctx = api.Context(0)
+    g = torch.from_numpy(guides).cuda()
+    pad = 64                                                    # floats of canary either side of the result
+    for it in (1, 2, 4, 5):
+        outs = []
+        for flags in (0, api.RT_RECON_NO_LDS):
+            src = torch.from_numpy(low).cuda()
+            box = torch.full((H * W * 4 + 2 * pad,), -7.0, dtype=torch.float32, device="cuda")
+            torch.cuda.synchronize()
+            ctx.reconstruct(src.data_ptr(), g.data_ptr(), W, H, box.data_ptr() + 4 * pad, iterations=it, flags=flags)
+            ctx.stats()
+            b = box.cpu().numpy()
+            assert (b[:pad] == -7.0).all() and (b[-pad:] == -7.0).all(), (size, it, flags)
+            outs.append(b[pad:-pad].reshape(H, W, 4))
+        assert np.array_equal(outs[0], outs[1]), (size, it)
+        full = dict(R.DEFAULTS); full.update(iterations=it)
+        want = R.reconstruct(low, g0, alb, ids, **full)
+        assert (outs[0][..., 3] == spp).all()
+        assert np.abs(outs[0][..., :3] - want[..., :3]).max() / spp <= 1e-4 * max(1.0, float(want[..., :3].max() / spp)), (size, it)
+    ctx.close()
