@@ -232,3 +232,47 @@ def test_reconstruction_of_ragged_frames(api, size):
         assert (outs[0][..., 3] == spp).all()
         assert np.abs(outs[0][..., :3] - want[..., :3]).max() / spp <= 1e-4 * max(1.0, float(want[..., :3].max() / spp)), (size, it)
     ctx.close()
+
+
+@pytest.mark.parametrize("sizes", [((2, 2), (2, 2)), ((2, 2), (8, 8)), ((3, 5), (7, 9)), ((17, 9), (33, 35)), ((31, 8), (124, 32))])
+def test_upscaling_of_ragged_frames(api, sizes):
+    """The smallest frames rt_upscale takes, the same size in and out, the largest ratio and ratios that are not
+    whole numbers, on made-up guides: the restatement's frame, and nothing outside the result is touched."""
+    import torch
+    from oracle import reconstruct as R
+    (lw, lh), (W, H) = sizes
+    rng = np.random.default_rng(lw * 7919 + W)
+    spp = 4
+
+    def made_up(w, h):
+        ids = rng.integers(-1, 3, (h, w)).astype(np.int32)
+        n = rng.normal(size=(h, w, 3)); n /= np.linalg.norm(n, axis=-1, keepdims=True)
+        g0 = np.concatenate([n, rng.uniform(1.0, 20.0, (h, w, 1))], -1).astype(np.float32)
+        g0[ids < 0] = 0.0
+        alb = rng.uniform(0.05, 1.0, (h, w, 3)).astype(np.float32)
+        alb[ids < 0] = 1.0
+        both = np.zeros((2, h, w, 4), np.float32)
+        both[0] = g0
+        both[1, ..., :3] = alb
+        both[1, ..., 3] = ids.view(np.float32)
+        return g0, alb, ids, torch.from_numpy(both).cuda()
+
+    g0l, albl, idl, gl_t = made_up(lw, lh)
+    g0h, albh, idh, gh_t = made_up(W, H)
+    low = np.concatenate([rng.uniform(0.0, 2.0, (lh, lw, 3)) * spp, np.full((lh, lw, 1), float(spp))], -1).astype(np.float32)
+    ctx = api.Context(0)
+    pad = 64
+    box = torch.full((H * W * 4 + 2 * pad,), -7.0, dtype=torch.float32, device="cuda")
+    low_t = torch.from_numpy(low).cuda()
+    torch.cuda.synchronize()
+    ctx.upscale(low_t.data_ptr(), gl_t.data_ptr(), lw, lh, gh_t.data_ptr(), W, H, box.data_ptr() + 4 * pad)
+    ctx.stats()
+    b = box.cpu().numpy()
+    assert (b[:pad] == -7.0).all() and (b[-pad:] == -7.0).all()
+    got = b[pad:-pad].reshape(H, W, 4)
+    want = R.upscale(low, g0l, albl, idl, g0h, albh, idh)
+    assert (got[..., 3] == spp).all()
+    err = np.abs(got[..., :3] - want[..., :3]) / spp
+    # (a pixel whose summed weight stands within rounding of the fall-back threshold may take the other branch)
+    assert (err > 1e-4 * max(1.0, float(want[..., :3].max() / spp))).sum() <= max(1, int(1e-3 * W * H)), (sizes, float(err.max()))
+    ctx.close()
