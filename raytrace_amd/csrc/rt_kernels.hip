@@ -478,16 +478,17 @@ __device__ __forceinline__ void hit_always(const DScene& sc, lds_crect* staged, 
         // rect this is and which axis its plane cuts are wave-uniform branches: one copy of the test
         // per plane axis, each on the ray's components themselves
         bool hit;
-        const int ka = __builtin_amdgcn_readfirstlane(r.axes & 3);
-        if (INST && (r.axes >> 8)) {         // instance: a rotation keeps |d|, so t means the same
-            const ObjRay q = to_object(sc.xforms[(r.axes >> 8) - 1], o, d, ka, sc.rect_k[i]);
+        const int axes = __builtin_amdgcn_readfirstlane(r.axes);      // (the same in every lane: tests on it are scalar)
+        const int ka = axes & 3;
+        if (INST && (axes >> 8)) {           // instance: a rotation keeps |d|, so t means the same
+            const ObjRay q = to_object(sc.xforms[(axes >> 8) - 1], o, d, ka, sc.rect_k[i]);
             if (ka == 0) hit = rect_test<0>(r, q.num, polished_rcp(q.d.x), q.o, q.d, t_min, kInf, t);
             else if (ka == 1) hit = rect_test<1>(r, q.num, polished_rcp(q.d.y), q.o, q.d, t_min, kInf, t);
             else hit = rect_test<2>(r, q.num, polished_rcp(q.d.z), q.o, q.d, t_min, kInf, t);
         } else {
             // the distance to the plane: in float when the plane coordinate is a float (the
             // subtraction is then as good as the double one rounded), else in double
-            const bool k64 = (r.axes & 64) != 0;
+            const bool k64 = (axes & 64) != 0;
             if (ka == 0) hit = rect_test<0>(r, k64 ? (float)(sc.rect_k[i] - (double)o.x) : r.k - o.x, inv_d.x, o, d, t_min, kInf, t);
             else if (ka == 1) hit = rect_test<1>(r, k64 ? (float)(sc.rect_k[i] - (double)o.y) : r.k - o.y, inv_d.y, o, d, t_min, kInf, t);
             else hit = rect_test<2>(r, k64 ? (float)(sc.rect_k[i] - (double)o.z) : r.k - o.z, inv_d.z, o, d, t_min, kInf, t);
